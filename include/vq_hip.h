@@ -1,0 +1,114 @@
+/*
+ * vq_hip.h -- C ABI of libvqhip.so, the MI355X (gfx950) implementation of the image
+ * vector-quantisation hot path of VQ_Full.py: block extraction, L1 nearest-codeword
+ * search, LBG split / centroid update, decode.
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer owned by the caller unless its name starts with h_.
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it and
+ *     returns without synchronising.  No entry point allocates or frees device memory: all
+ *     scratch comes in through the `ws` argument (size from vq_workspace_bytes()).
+ *   - Return value: 0 on success, a negative VQ_E_* code on failure; vq_last_error()
+ *     returns a thread-local message for the last failure on the calling thread.
+ *   - The library keeps no mutable global state; it may be called from any host thread.
+ *   - Block vectors are rows of an (N, d) uint8 matrix, d = block_h * block_w * C, element
+ *     order (row-in-block, col-in-block, channel), vectors in row-major block-grid order.
+ *     Codebooks are (K, d) IEEE doubles, row-major.
+ *   - `mode`: VQ_MODE_FAST and VQ_MODE_EXACT return identical results (same labels, same
+ *     fp64 distances).  FAST filters with a 16-bit fixed-point SAD and re-checks every
+ *     near-tie in sequential fp64; EXACT evaluates every distance in sequential fp64.
+ */
+#ifndef VQ_HIP_H
+#define VQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VQ_OK             0
+#define VQ_E_INVALID     -1   /* bad argument (null pointer, non-positive size, k > N ...) */
+#define VQ_E_HIP         -2   /* a HIP runtime call failed; message holds hipGetErrorString */
+#define VQ_E_WORKSPACE   -3   /* ws is null or smaller than vq_workspace_bytes(K, d) */
+#define VQ_E_UNSUPPORTED -4   /* shape outside what the kernels handle */
+
+#define VQ_MODE_EXACT 0
+#define VQ_MODE_FAST  1
+
+#define VQ_PAD_EDGE 0   /* replicate last row / column (VQ_Full.py:28-33) */
+#define VQ_PAD_ZERO 1   /* constant 0 (old/CodeBook_VQ.py:26) */
+
+/* ABI version of this header; bumped on any signature change. */
+int vq_abi_version(void);
+
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char *vq_last_error(void);
+
+/* Bytes of device scratch that vq_encode_l1 / vq_lbg_accum / vq_decode_u8 need for a (K, d)
+ * codebook.  Pure host arithmetic. */
+size_t vq_workspace_bytes(int K, int d);
+
+/* Block extraction.  Replaces Codebook.__init__'s padding (VQ_Full.py:23-33) and
+ * Codebook.image_to_blocks (VQ_Full.py:51-57): img is (H, W, C) uint8, padded on the bottom /
+ * right to multiples of (bh, bw) with pad_mode, and cut into
+ * ceil(H/bh) * ceil(W/bw) vectors of d = bh*bw*C bytes written to blocks. */
+int vq_blocks_u8(const uint8_t *img, int H, int W, int C, int bh, int bw, int pad_mode,
+                 uint8_t *blocks, void *stream);
+
+/* Column sums of the block matrix: sums[e] = sum_n blocks[n, e] (exact, uint64).  The initial
+ * centroid np.mean(self.blocks, axis=0) of VQ_Full.py:67 is sums[e] / N.  sums is overwritten. */
+int vq_colsum_u8(const uint8_t *blocks, int64_t N, int d, uint64_t *sums, void *stream);
+
+/* Nearest codeword.  Replaces cdist(..., 'cityblock') + np.argmin of Codebook.compress
+ * (VQ_Full.py:124-125): labels[n] = argmin_k sum_e |double(blocks[n,e]) - cb[k,e]| with the sum
+ * taken left to right in fp64 and the lowest k winning ties.  min_dist (nullable) receives the
+ * winning fp64 distance per vector (the values VQ_Full.py:89 gathers). */
+int vq_encode_l1(const uint8_t *blocks, int64_t N, int d, const double *cb, int K,
+                 int32_t *labels, double *min_dist, int mode, void *ws, size_t ws_bytes, void *stream);
+
+/* One LBG assignment pass, fused.  Replaces VQ_Full.py:77-90 up to the division: assigns every
+ * vector as vq_encode_l1 does, then ADDS into sums[k*d+e] the byte sums of cluster k, into
+ * counts[k] its member count, and OVERWRITES dist_sum[0] with the fp64 sum of the winning
+ * distances (distortion = dist_sum / N).  sums and counts are accumulated into, so the caller
+ * zeroes them first (and may all-reduce them across GPUs afterwards).  labels is nullable. */
+int vq_lbg_accum(const uint8_t *blocks, int64_t N, int d, const double *cb, int K,
+                 uint64_t *sums, uint64_t *counts, double *dist_sum, int32_t *labels, int mode,
+                 void *ws, size_t ws_bytes, void *stream);
+
+/* Per-cluster byte sums and counts for a given labelling (the inputs of np.mean(members, axis=0),
+ * VQ_Full.py:82-84).  Accumulates into sums / counts like vq_lbg_accum. */
+int vq_accum_labels(const uint8_t *blocks, int64_t N, int d, const int32_t *labels, int K,
+                    uint64_t *sums, uint64_t *counts, void *stream);
+
+/* Centroid update.  Replaces VQ_Full.py:81-86: cb_new[k] = sums[k] / counts[k] (one IEEE fp64
+ * divide of the exact integer sum) for a non-empty cluster, cb_old[k] for an empty one.
+ * cb_new may alias cb_old. */
+int vq_lbg_finalize(const uint64_t *sums, const uint64_t *counts, const double *cb_old, int K, int d,
+                    double *cb_new, void *stream);
+
+/* Split.  Replaces VQ_Full.py:71-73: cb2[0:K] = cb * (1 + eps), cb2[K:2K] = cb * (1 - eps);
+ * cb2 holds 2*K*d doubles and must not overlap cb. */
+int vq_lbg_split(const double *cb, int K, int d, double eps, double *cb2, void *stream);
+
+/* Decode.  Replaces the loop of Codebook.decompress (VQ_Full.py:157-169):
+ * img[r*bh+i, q*bw+j, ch] = (uint8) trunc(cb[labels[r*nc+q], i, j, ch]) with the conversion
+ * wrapping modulo 256 as numpy's does; img is (nr*bh, nc*bw, C) uint8 (padded size, not cropped).
+ * Labels outside [0, K) make the call undefined, as an out-of-range index does in the reference. */
+int vq_decode_u8(const int32_t *labels, int nr, int nc, const double *cb, int K, int bh, int bw, int C,
+                 uint8_t *img, void *ws, size_t ws_bytes, void *stream);
+
+/* Label bit-packer.  Replaces VQ_Full.py:134-147: labels in order, ceil(log2 K) bits each,
+ * MSB first, last byte zero-padded on the right.  out holds vq_packed_bytes(N, K) bytes. */
+size_t vq_packed_bytes(int64_t N, int K);
+int vq_pack_labels(const int32_t *labels, int64_t N, int K, uint8_t *out, void *stream);
+
+/* Inverse of vq_pack_labels (no counterpart in the reference, whose decoder reads the JSON
+ * labels; provided so that the .bin stream can be decoded on the GPU). */
+int vq_unpack_labels(const uint8_t *packed, int64_t N, int K, int32_t *labels, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQ_HIP_H */

@@ -1,0 +1,70 @@
+"""The C-ABI library loads without a GPU and exports exactly what include/vq_hip.h declares."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "vq_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vq_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_surface():
+    names = declared_functions()
+    for must in ("vq_blocks_u8", "vq_colsum_u8", "vq_encode_l1", "vq_lbg_accum", "vq_lbg_finalize", "vq_lbg_split",
+                 "vq_decode_u8", "vq_pack_labels", "vq_workspace_bytes", "vq_last_error", "vq_abi_version"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from vector_quantization_amd import _lib
+    lib = ctypes.CDLL(_lib.library_path())
+    for name in declared_functions():
+        assert hasattr(lib, name), f"libvqhip.so does not export {name}"
+
+
+def test_python_binding_covers_the_header():
+    from vector_quantization_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared_functions()
+    assert _lib.lib.vq_abi_version() == _lib.ABI_VERSION
+
+
+def test_host_only_entry_points():
+    """Pure host arithmetic (no GPU work): workspace and packed sizes, argument validation."""
+    from vector_quantization_amd import _lib
+    lib = _lib.lib
+    assert lib.vq_workspace_bytes(256, 16) >= 256 * 16 * 8 + 256 * 16 * 2
+    assert lib.vq_workspace_bytes(0, 16) == 0
+    assert lib.vq_packed_bytes(1000, 256) == 1000
+    assert lib.vq_packed_bytes(1000, 5) == (1000 * 3 + 7) // 8
+    assert lib.vq_packed_bytes(1000, 1) == 0
+    # validation happens before any HIP call, so these run on a CPU-only machine
+    rc = lib.vq_encode_l1(None, 10, 16, None, 4, None, None, 1, None, 0, None)
+    assert rc == _lib.VQ_E_INVALID and "null" in _lib.last_error()
+    rc = lib.vq_blocks_u8(ctypes.c_void_p(16), 0, 4, 1, 2, 2, 0, ctypes.c_void_p(16), None)
+    assert rc == _lib.VQ_E_INVALID
+    rc = lib.vq_lbg_split(ctypes.c_void_p(16), 0, 4, 0.01, ctypes.c_void_p(16), None)
+    assert rc == _lib.VQ_E_INVALID
+
+
+def test_engine_refuses_to_run_without_gpu():
+    import pytest
+    import torch
+    from vector_quantization_amd import HipEngine
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        HipEngine()
+
+
+def test_package_does_not_reference_the_oracle():
+    """The product must never import, load or shell out to anything under oracle/."""
+    pkg = os.path.join(ROOT, "vector_quantization_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".sh")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.lower(), f"{f} mentions the oracle"

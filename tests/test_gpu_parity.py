@@ -1,0 +1,362 @@
+"""Parity of the HIP path (through the C ABI, via HipEngine) against the CPU oracle and the
+golden fixtures produced by the reference.  Bar: bit-exact for labels, pixels, packed bits,
+integer sums, codebooks (fp64) and per-vector distances; distortion sums within 1e-12 relative
+(the device adds the exact per-vector distances in a different order than numpy).
+"""
+import numpy as np
+import pytest
+import torch
+
+from vqtest_util import TRAIN_CASES, load_golden, stage_end_codebooks
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from vector_quantization_amd import HipEngine
+    return HipEngine("cuda:0", mode="fast")
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to("cuda:0")
+
+
+# ---------------------------------------------------------------------------------------------------
+# block extraction
+# ---------------------------------------------------------------------------------------------------
+def test_blocks_golden(eng, train_case):
+    g = train_case
+    b = eng.blocks_from_image(dev(g["img"]), int(g["bh"]), int(g["bw"]))
+    assert np.array_equal(b.cpu().numpy(), g["blocks"])
+
+
+@pytest.mark.parametrize("shape,bh,bw", [((7, 5, 3), 2, 2), ((33, 17, 1), 4, 4), ((64, 64, 3), 8, 8), ((9, 9, 1), 3, 3),
+                                         ((5, 7, 3), 1, 1), ((16, 20, 2), 4, 2), ((3, 3, 1), 4, 4), ((130, 67, 3), 3, 5)])
+@pytest.mark.parametrize("pad_mode", [0, 1])
+def test_blocks_ragged(eng, oracle, shape, bh, bw, pad_mode):
+    rng = np.random.default_rng(hash((shape, bh, bw)) & 0xffff)
+    img = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    got = eng.blocks_from_image(dev(img), bh, bw, pad_mode).cpu().numpy()
+    assert np.array_equal(got, oracle.blocks_u8(img, bh, bw, pad_mode))
+
+
+def test_colsum(eng, oracle, train_case):
+    g = train_case
+    s = eng.colsum(dev(g["blocks"])).cpu().numpy().astype(np.uint64)
+    assert np.array_equal(s, oracle.colsum_u8(g["blocks"]))
+
+
+# ---------------------------------------------------------------------------------------------------
+# nearest codeword
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", [0, 1])
+def test_encode_golden(eng, train_case, mode):
+    g = train_case
+    labels, mind = eng.encode(dev(g["blocks"]), dev(g["codebook"]), want_dist=True, mode=mode)
+    assert np.array_equal(labels.cpu().numpy().astype(np.int64).reshape(g["labels"].shape), g["labels"])
+    if "it_cb_in" in g:
+        labels, mind = eng.encode(dev(g["blocks"]), dev(g["it_cb_in"]), want_dist=True, mode=mode)
+        assert np.array_equal(labels.cpu().numpy().astype(np.int64), g["it_labels"])
+        assert np.array_equal(mind.cpu().numpy(), g["it_mind"])
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_encode_every_stage_codebook(eng, oracle, train_case, mode):
+    g = train_case
+    blocks = dev(g["blocks"])
+    for cb in stage_end_codebooks(g):
+        want_l, want_d = oracle.encode_l1(g["blocks"], cb, want_dist=True)
+        got_l, got_d = eng.encode(blocks, dev(cb), want_dist=True, mode=mode)
+        assert np.array_equal(got_l.cpu().numpy(), want_l)
+        assert np.array_equal(got_d.cpu().numpy(), want_d)
+
+
+DIMS = [1, 2, 3, 4, 5, 8, 11, 12, 16, 17, 24, 27, 32, 48, 63, 64, 75, 96, 100, 128, 147, 192, 200]
+
+
+@pytest.mark.parametrize("d", DIMS)
+def test_encode_random_dims(eng, oracle, d):
+    """Every template bucket of the fast kernel, odd dimensions, and d beyond the fast kernels."""
+    rng = np.random.default_rng(d)
+    N, K = 3001, 37
+    blocks = rng.integers(0, 256, size=(N, d), dtype=np.uint8)
+    cb = rng.random((K, d)) * 255.0
+    want_l, want_d = oracle.encode_l1(blocks, cb, want_dist=True)
+    for mode in (0, 1):
+        got_l, got_d = eng.encode(dev(blocks), dev(cb), want_dist=True, mode=mode)
+        assert np.array_equal(got_l.cpu().numpy(), want_l), f"labels differ, d={d} mode={mode}"
+        assert np.array_equal(got_d.cpu().numpy(), want_d), f"distances differ, d={d} mode={mode}"
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 5, 64, 65, 255, 256, 257, 1024, 4096])
+def test_encode_codebook_sizes(eng, oracle, K):
+    rng = np.random.default_rng(K)
+    N, d = 2500, 16
+    blocks = rng.integers(0, 256, size=(N, d), dtype=np.uint8)
+    cb = rng.random((K, d)) * 255.0
+    want = oracle.encode_l1(blocks, cb)
+    got = eng.encode(dev(blocks), dev(cb)).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_encode_ties_and_duplicates(eng, oracle):
+    """Exact ties: duplicated codewords, integer codewords equidistant from integer pixels, and a
+    flat image; the lowest index must win, as numpy.argmin does."""
+    rng = np.random.default_rng(3)
+    d, K, N = 16, 64, 4096
+    cb = np.round(rng.random((K, d)) * 255.0)
+    cb[7] = cb[3]                       # duplicate rows
+    cb[40] = cb[3]
+    cb[10] = 0.0
+    cb[11] = 0.0                        # the zero twin of an all-zero centroid's split
+    cb[20] = cb[21][::-1].copy()        # a permutation: equal distance to a constant vector
+    blocks = rng.integers(0, 256, size=(N, d), dtype=np.uint8)
+    blocks[:512] = 0
+    blocks[512:1024] = 128
+    blocks[1024:1100] = cb[3].astype(np.uint8)
+    # midpoints between two integer codewords: exact fp64 ties by construction
+    mid = ((cb[30] + cb[31]) / 2).astype(np.uint8)
+    blocks[1100:1200] = mid
+    want_l, want_d = oracle.encode_l1(blocks, cb, want_dist=True)
+    for mode in (0, 1):
+        got_l, got_d = eng.encode(dev(blocks), dev(cb), want_dist=True, mode=mode)
+        assert np.array_equal(got_l.cpu().numpy(), want_l)
+        assert np.array_equal(got_d.cpu().numpy(), want_d)
+
+
+def test_encode_near_ties_need_fp64(eng, oracle):
+    """Codeword pairs whose distances to a vector differ by a few ulps of fp64: neither a 16-bit
+    filter nor fp32 can rank them; the fp64 re-check must reproduce the sequential-sum ranking."""
+    rng = np.random.default_rng(11)
+    d, N = 16, 2048
+    blocks = rng.integers(0, 256, size=(N, d), dtype=np.uint8)
+    base = rng.random((32, d)) * 255.0
+    cbs = [base]
+    for scale in (1e-13, 3e-13, 1e-12, 1e-9, 1e-6, 1e-3):
+        pert = base.copy()
+        # move mass between two coordinates so the L1 distance to most vectors changes by ~scale only
+        pert[:, 0] += scale
+        pert[:, 1] -= scale
+        cbs.append(pert)
+    cb = np.vstack(cbs[::-1])            # the perturbed copies come FIRST, the originals last
+    want_l, want_d = oracle.encode_l1(blocks, cb, want_dist=True)
+    for mode in (0, 1):
+        got_l, got_d = eng.encode(dev(blocks), dev(cb), want_dist=True, mode=mode)
+        assert np.array_equal(got_l.cpu().numpy(), want_l)
+        assert np.array_equal(got_d.cpu().numpy(), want_d)
+
+
+def test_encode_codebook_out_of_pixel_range(eng, oracle):
+    """Entries above 255 (255 * 1.01 kept by an empty cluster), far above 65535/2^s, and negative."""
+    rng = np.random.default_rng(5)
+    d, N = 12, 3000
+    blocks = rng.integers(0, 256, size=(N, d), dtype=np.uint8)
+    for top in (257.55, 300.0, 600.0, 70000.0, -5.0):
+        cb = rng.random((16, d)) * 255.0
+        cb[2] = top
+        cb[5, 3] = top
+        want = oracle.encode_l1(blocks, cb)
+        got = eng.encode(dev(blocks), dev(cb)).cpu().numpy()
+        assert np.array_equal(got, want), f"top={top}"
+
+
+def test_encode_empty_and_tiny(eng, oracle):
+    cb = np.arange(32, dtype=np.float64).reshape(2, 16)
+    got = eng.encode(dev(np.zeros((0, 16), dtype=np.uint8)), dev(cb))
+    assert got.numel() == 0
+    one = np.full((1, 16), 9, dtype=np.uint8)
+    assert np.array_equal(eng.encode(dev(one), dev(cb)).cpu().numpy(), oracle.encode_l1(one, cb))
+
+
+# ---------------------------------------------------------------------------------------------------
+# LBG pieces
+# ---------------------------------------------------------------------------------------------------
+def _check_iteration(eng, oracle, blocks, cb, mode):
+    want = oracle.lbg_iter(blocks, cb)
+    K, d = cb.shape
+    acc, dist, labels = eng.lbg_accum(dev(blocks), dev(cb), want_labels=True, mode=mode)
+    acc_h = acc.cpu().numpy().astype(np.uint64)
+    assert np.array_equal(labels.cpu().numpy(), want["labels"])
+    assert np.array_equal(acc_h[: K * d].reshape(K, d), want["sums"])
+    assert np.array_equal(acc_h[K * d:], want["counts"])
+    exact_sum = float(np.sum(want["min_dist"]))
+    assert abs(dist.item() - exact_sum) <= 1e-12 * max(exact_sum, 1.0)
+    new_cb = eng.lbg_finalize(acc, dev(cb)).cpu().numpy()
+    assert np.array_equal(new_cb, want["cb_out"])
+    return new_cb
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_lbg_iteration_golden(eng, oracle, train_case, mode):
+    g = train_case
+    if "it_cb_in" not in g:
+        pytest.skip("no iteration KAT")
+    new_cb = _check_iteration(eng, oracle, g["blocks"], g["it_cb_in"], mode)
+    assert np.array_equal(new_cb, g["it_cb_out"])
+
+
+@pytest.mark.parametrize("K,d", [(2, 16), (8, 4), (256, 16), (1024, 16), (2048, 16), (64, 48), (512, 192), (16, 200)])
+def test_lbg_iteration_shapes(eng, oracle, K, d):
+    """LDS-table, large-LDS-table and global-atomic accumulation paths; d beyond the fast kernels."""
+    rng = np.random.default_rng(K * 1000 + d)
+    N = 20000
+    blocks = rng.integers(0, 256, size=(N, d), dtype=np.uint8)
+    blocks[:3000] = blocks[0]            # a heavily populated cluster (LDS atomic conflicts)
+    cb = rng.random((K, d)) * 255.0
+    _check_iteration(eng, oracle, blocks, cb, 1)
+
+
+def test_accum_labels(eng, oracle):
+    rng = np.random.default_rng(9)
+    N, d, K = 5000, 12, 16
+    blocks = rng.integers(0, 256, size=(N, d), dtype=np.uint8)
+    labels = rng.integers(0, K, size=N).astype(np.int32)
+    acc = eng.accum_labels(dev(blocks), dev(labels), K).cpu().numpy().astype(np.uint64)
+    sums, counts = oracle.accumulate(blocks, labels, K)
+    assert np.array_equal(acc[: K * d].reshape(K, d), sums)
+    assert np.array_equal(acc[K * d:], counts)
+
+
+def test_split_bitexact(eng, oracle):
+    rng = np.random.default_rng(2)
+    cb = rng.random((300, 48)) * 255.0
+    got = eng.lbg_split(dev(cb), 0.01).cpu().numpy()
+    assert np.array_equal(got, oracle.split(cb, 0.01))
+    assert np.array_equal(got, np.vstack((cb * (1 + 0.01), cb * (1 - 0.01))))
+
+
+def test_finalize_division_bitexact(eng, oracle):
+    """One IEEE fp64 divide per element: compare against the host's correctly rounded division on
+    many (sum, count) pairs, including sums beyond 2^32 and empty clusters."""
+    rng = np.random.default_rng(4)
+    K, d = 4096, 16
+    counts = rng.integers(0, 1 << 28, size=K).astype(np.uint64)
+    counts[::17] = 0
+    sums = (rng.integers(0, 256, size=(K, d)).astype(np.uint64) * counts[:, None]
+            + rng.integers(0, 1 << 20, size=(K, d)).astype(np.uint64))
+    old = rng.random((K, d)) * 300.0
+    acc = np.concatenate([sums.reshape(-1), counts]).astype(np.int64)
+    got = eng.lbg_finalize(dev(acc), dev(old)).cpu().numpy()
+    assert np.array_equal(got, oracle.finalize(sums, counts, old))
+
+
+# ---------------------------------------------------------------------------------------------------
+# full training, through the reference-shaped Codebook class
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["fast", "exact"])
+def test_codebook_class_matches_reference(tmp_path, train_case, mode, capsys):
+    from vector_quantization_amd import Codebook
+    g = train_case
+    if mode == "exact" and g["name"] not in ("luffy_2x2_k16", "man_2x2_k5", "synth_iid_128_4x4_k32"):
+        pytest.skip("exact mode is checked on the small cases")
+    cb = Codebook.from_array(g["img"], int(g["bh"]), int(g["bw"]), base_name=g["name"], device="cuda:0", mode=mode,
+                             output_dir=str(tmp_path))
+    assert np.array_equal(cb.blocks, g["blocks"])
+    final = cb.generate_codebook(int(g["k"]))
+    out = capsys.readouterr().out
+    assert cb.training.iters_per_stage == list(g["iters_per_stage"])
+    assert cb.training.converged_iter == list(g["converged_iter"])
+    assert np.allclose(cb.training.distortions, g["distortions"], rtol=1e-12, atol=0)
+    assert np.array_equal(cb.codebook, g["codebook"])                      # bit-exact codebook
+    assert np.array_equal(np.array(final).reshape(g["codebook"].shape), g["codebook"])
+    ref_conv = [l for l in str(g["log"]).splitlines() if l.startswith("Converged")]
+    got_conv = [l for l in out.splitlines() if l.startswith("Converged")]
+    assert got_conv == ref_conv                                             # same iteration, same 3-dp distortion
+    labels = cb.compress()
+    assert labels.dtype == np.int64 and np.array_equal(labels, g["labels"])
+    assert np.array_equal(np.fromfile(cb.labels_bin, dtype=np.uint8), g["labels_bin"])
+    import hashlib
+    assert hashlib.sha256(open(cb.codebook_json, "rb").read()).hexdigest() == str(g["codebook_json_sha256"])
+    assert hashlib.sha256(open(cb.labels_json, "rb").read()).hexdigest() == str(g["labels_json_sha256"])
+    assert hashlib.sha256(open(cb.codebook_txt, "rb").read()).hexdigest() == str(g["codebook_txt_sha256"])
+    arr = Codebook.decompress(cb.labels_json, cb.codebook_json, cb.reconstructed_path, device="cuda:0")
+    assert arr.dtype == np.uint8 and np.array_equal(arr, g["decoded"])
+
+
+# ---------------------------------------------------------------------------------------------------
+# decode, bit stream
+# ---------------------------------------------------------------------------------------------------
+def test_decode_golden(eng, train_case):
+    g = train_case
+    C = g["img"].shape[2]
+    img = eng.decode(dev(g["labels"], torch.int32), dev(g["codebook"]), int(g["bh"]), int(g["bw"]), C)
+    assert np.array_equal(img.cpu().numpy(), g["decoded"])
+
+
+def test_decode_known_answer(eng):
+    g = load_golden("decode_kat_2x2")
+    img = eng.decode(dev(g["labels"], torch.int32), dev(g["codebook"].reshape(4, 4)), 2, 2, 1)
+    assert np.array_equal(img.cpu().numpy()[:, :, 0], g["img"])
+
+
+def test_decode_cast_table(eng):
+    g = load_golden("cast_f64_u8")
+    vals = g["vals"]
+    labels = np.arange(len(vals), dtype=np.int32).reshape(1, -1)
+    img = eng.decode(dev(labels), dev(vals.reshape(-1, 1)), 1, 1, 1)
+    assert np.array_equal(img.cpu().numpy().reshape(-1), g["cast"])
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 8, 17, 256, 1000, 4096])
+def test_pack_unpack(eng, oracle, K):
+    rng = np.random.default_rng(K)
+    for N in (0, 1, 7, 8, 9, 1001, 65537):
+        labels = rng.integers(0, K, size=N).astype(np.int32)
+        packed = eng.pack_labels(dev(labels), K)
+        assert np.array_equal(packed.cpu().numpy(), oracle.pack_labels(labels, K))
+        back = eng.unpack_labels(packed, N, K)
+        assert np.array_equal(back.cpu().numpy(), labels)
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE-size properties (no oracle at this size: size-independent checks)
+# ---------------------------------------------------------------------------------------------------
+def _structured(h, w, seed):
+    g = torch.Generator(device="cuda:0").manual_seed(seed)
+    y = torch.arange(h, device="cuda:0", dtype=torch.float32)[:, None]
+    x = torch.arange(w, device="cuda:0", dtype=torch.float32)[None, :]
+    v = (128 + 64 * torch.sin(2 * np.pi * x / 257) * torch.cos(2 * np.pi * y / 181)
+         + 32 * torch.sin(2 * np.pi * (x + y) / 1021) + 16 * torch.randn((h, w), device="cuda:0", generator=g))
+    return v.clamp(0, 255).to(torch.uint8)
+
+
+def test_full_size_encode_decode_properties(eng, oracle):
+    """8192 x 8192 grayscale, 4x4 blocks, K=256 (BASELINE config 2)."""
+    from vector_quantization_amd import train_lbg
+    img = _structured(8192, 8192, 0)
+    blocks = eng.blocks_from_image(img, 4, 4)
+    assert blocks.shape == (2048 * 2048, 16)
+    crop = eng.blocks_from_image(img[:1024, :1024].contiguous(), 4, 4)
+    cb = train_lbg(eng, crop, 256, log=None).codebook
+    lab_fast = eng.encode(blocks, cb, mode=1)
+    lab_exact = eng.encode(blocks, cb, mode=0)
+    assert torch.equal(lab_fast, lab_exact)                       # filter + re-check == all-fp64 search
+    # a sample against the CPU oracle
+    idx = torch.randperm(blocks.shape[0], device="cuda:0")[:20000]
+    want = oracle.encode_l1(blocks[idx].cpu().numpy(), cb.cpu().numpy())
+    assert np.array_equal(lab_fast[idx].cpu().numpy(), want)
+    # decode, then encode the decoded image again: labels are a fixed point wherever the codeword is
+    # integral after truncation; in general the re-encoded image decodes to the same pixels
+    dec = eng.decode(lab_fast.reshape(2048, 2048), cb, 4, 4, 1)
+    assert dec.shape == (8192, 8192, 1)
+    blocks2 = eng.blocks_from_image(dec, 4, 4)
+    cb8 = torch.from_numpy(oracle.decode_u8(np.arange(256, dtype=np.int32).reshape(1, -1), cb.cpu().numpy(), 4, 4, 1)
+                           ).to("cuda:0")                           # the truncated codebook as a 4 x 1024 strip
+    rows = blocks2.reshape(2048, 2048, 16)
+    strip = eng.blocks_from_image(cb8, 4, 4)                        # (256, 16) truncated codewords
+    assert torch.equal(rows.reshape(-1, 16), strip[lab_fast.long()])
+    # bit stream round trip at full size
+    packed = eng.pack_labels(lab_fast, 256)
+    assert packed.numel() == blocks.shape[0]
+    assert torch.equal(eng.unpack_labels(packed, blocks.shape[0], 256), lab_fast)
+    # accumulation is a partition of the data: counts add up, sums add up to the column sums
+    acc, dist = eng.lbg_accum(blocks, cb)
+    assert int(acc[256 * 16:].sum().item()) == blocks.shape[0]
+    assert torch.equal(acc[: 256 * 16].reshape(256, 16).sum(0), eng.colsum(blocks))
+    # run-to-run determinism, including the fp64 distance sum
+    acc2, dist2 = eng.lbg_accum(blocks, cb)
+    assert torch.equal(acc, acc2) and dist.item() == dist2.item()

@@ -1,0 +1,170 @@
+"""HipEngine: the device side of the VQ hot path, one object per GPU.
+
+PyTorch-ROCm tensors are used only as device buffers (data_ptr) and for the current HIP stream;
+every computation is a call through the C ABI of libvqhip.so.  uint64 sums and counts live in
+int64 tensors (values stay far below 2^63).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import lib, check, VQ_MODE_EXACT, VQ_MODE_FAST, VQ_PAD_EDGE, VQ_PAD_ZERO  # noqa: F401
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+class HipEngine:
+    """Launches the HIP kernels on one device.  Not thread-safe per instance (it caches its
+    workspace); use one engine per host thread, or one per GPU in a multi-process job."""
+
+    def __init__(self, device=None, mode="fast"):
+        if not torch.cuda.is_available():
+            raise RuntimeError(
+                "vector_quantization_amd needs a ROCm GPU (torch.cuda.is_available() is False); "
+                "there is no CPU fallback")
+        self.device = torch.device(device if device is not None else "cuda:0")
+        if self.device.type != "cuda":
+            raise ValueError(f"HipEngine needs a cuda/ROCm device, got {self.device}")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        if mode not in ("fast", "exact"):
+            raise ValueError("mode must be 'fast' or 'exact'")
+        self.mode = VQ_MODE_FAST if mode == "fast" else VQ_MODE_EXACT
+        self._ws = None
+
+    # -- plumbing ----------------------------------------------------------------------------
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _workspace(self, K, d):
+        need = lib.vq_workspace_bytes(int(K), int(d))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _dev(self, t, dtype):
+        if t.device != self.device or t.dtype != dtype or not t.is_contiguous():
+            t = t.to(device=self.device, dtype=dtype).contiguous()
+        return t
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.device)
+
+    # -- block extraction (VQ_Full.py:23-33, 51-57) ----------------------------------------------
+    def blocks_from_image(self, img, bh, bw, pad_mode=VQ_PAD_EDGE):
+        img = self._dev(img, torch.uint8)
+        if img.dim() == 2:
+            img = img.unsqueeze(-1)
+        H, W, C = img.shape
+        if bh <= 0 or bw <= 0:
+            raise ValueError("Block height and width must be positive integers.")
+        nr, nc = -(-H // bh), -(-W // bw)
+        blocks = torch.empty((nr * nc, bh * bw * C), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib.vq_blocks_u8(_ptr(img), H, W, C, bh, bw, pad_mode, _ptr(blocks), self._stream()),
+                  "vq_blocks_u8")
+        return blocks
+
+    # -- initial centroid sums (VQ_Full.py:67) -----------------------------------------------------
+    def colsum(self, blocks):
+        N, d = blocks.shape
+        sums = torch.empty(d, dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib.vq_colsum_u8(_ptr(blocks), N, d, _ptr(sums), self._stream()), "vq_colsum_u8")
+        return sums
+
+    # -- nearest codeword (VQ_Full.py:124-125) -----------------------------------------------------
+    def encode(self, blocks, cb, want_dist=False, mode=None):
+        N, d = blocks.shape
+        cb = self._dev(cb, torch.float64)
+        K = cb.shape[0]
+        labels = torch.empty(N, dtype=torch.int32, device=self.device)
+        mind = torch.empty(N, dtype=torch.float64, device=self.device) if want_dist else None
+        ws = self._workspace(K, d)
+        with torch.cuda.device(self.device):
+            check(lib.vq_encode_l1(_ptr(blocks), N, d, _ptr(cb), K, _ptr(labels), _ptr(mind),
+                                   self.mode if mode is None else mode, _ptr(ws), ws.numel(), self._stream()),
+                  "vq_encode_l1")
+        return (labels, mind) if want_dist else labels
+
+    # -- fused LBG assignment + accumulation (VQ_Full.py:77-90) -------------------------------------
+    def lbg_accum(self, blocks, cb, want_labels=False, mode=None):
+        """Returns (acc, dist_sum[, labels]); acc is one int64 buffer [K*d sums | K counts] so that a
+        multi-GPU job can all-reduce it in one collective."""
+        N, d = blocks.shape
+        cb = self._dev(cb, torch.float64)
+        K = cb.shape[0]
+        acc = torch.zeros(K * d + K, dtype=torch.int64, device=self.device)
+        dist = torch.empty(1, dtype=torch.float64, device=self.device)
+        labels = torch.empty(N, dtype=torch.int32, device=self.device) if want_labels else None
+        ws = self._workspace(K, d)
+        sums, counts = acc[: K * d], acc[K * d:]
+        with torch.cuda.device(self.device):
+            check(lib.vq_lbg_accum(_ptr(blocks), N, d, _ptr(cb), K, _ptr(sums), _ptr(counts), _ptr(dist),
+                                   _ptr(labels), self.mode if mode is None else mode, _ptr(ws), ws.numel(),
+                                   self._stream()), "vq_lbg_accum")
+        return (acc, dist, labels) if want_labels else (acc, dist)
+
+    def accum_labels(self, blocks, labels, K):
+        N, d = blocks.shape
+        acc = torch.zeros(K * d + K, dtype=torch.int64, device=self.device)
+        labels = self._dev(labels, torch.int32)
+        with torch.cuda.device(self.device):
+            check(lib.vq_accum_labels(_ptr(blocks), N, d, _ptr(labels), K, _ptr(acc[: K * d]), _ptr(acc[K * d:]),
+                                      self._stream()), "vq_accum_labels")
+        return acc
+
+    # -- centroid update / split (VQ_Full.py:81-86, 71-73) -------------------------------------------
+    def lbg_finalize(self, acc, cb_old):
+        cb_old = self._dev(cb_old, torch.float64)
+        K, d = cb_old.shape
+        cb_new = torch.empty_like(cb_old)
+        with torch.cuda.device(self.device):
+            check(lib.vq_lbg_finalize(_ptr(acc[: K * d]), _ptr(acc[K * d:]), _ptr(cb_old), K, d, _ptr(cb_new),
+                                      self._stream()), "vq_lbg_finalize")
+        return cb_new
+
+    def lbg_split(self, cb, eps):
+        cb = self._dev(cb, torch.float64)
+        K, d = cb.shape
+        cb2 = torch.empty((2 * K, d), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib.vq_lbg_split(_ptr(cb), K, d, float(eps), _ptr(cb2), self._stream()), "vq_lbg_split")
+        return cb2
+
+    # -- decode (VQ_Full.py:157-169) -------------------------------------------------------------------
+    def decode(self, labels, cb, bh, bw, C):
+        labels = self._dev(labels, torch.int32)
+        nr, nc = labels.shape
+        cb = self._dev(cb, torch.float64).reshape(-1, bh * bw * C)
+        K = cb.shape[0]
+        img = torch.empty((nr * bh, nc * bw, C), dtype=torch.uint8, device=self.device)
+        ws = self._workspace(K, bh * bw * C)
+        with torch.cuda.device(self.device):
+            check(lib.vq_decode_u8(_ptr(labels), nr, nc, _ptr(cb), K, bh, bw, C, _ptr(img), _ptr(ws), ws.numel(),
+                                   self._stream()), "vq_decode_u8")
+        return img
+
+    # -- label bit stream (VQ_Full.py:134-147) -----------------------------------------------------------
+    def pack_labels(self, labels, K):
+        labels = self._dev(labels, torch.int32).reshape(-1)
+        N = labels.numel()
+        nbytes = lib.vq_packed_bytes(N, int(K))
+        out = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib.vq_pack_labels(_ptr(labels), N, int(K), _ptr(out), self._stream()), "vq_pack_labels")
+        return out
+
+    def unpack_labels(self, packed, N, K):
+        packed = self._dev(packed, torch.uint8)
+        need = lib.vq_packed_bytes(int(N), int(K))
+        if packed.numel() < need:
+            raise ValueError(f"packed stream has {packed.numel()} bytes, {need} needed for N={N}, K={K}")
+        labels = torch.empty(int(N), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib.vq_unpack_labels(_ptr(packed), int(N), int(K), _ptr(labels), self._stream()),
+                  "vq_unpack_labels")
+        return labels

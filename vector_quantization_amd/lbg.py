@@ -1,0 +1,117 @@
+"""LBG codebook training loop (host control flow of VQ_Full.py:60-98) over an engine.
+
+The engine does the per-vector work on its GPU; this module owns the split schedule, the
+stop rule and -- when the block vectors are sharded over several GPUs -- the per-iteration
+exchange: one all-reduce of the integer [sums | counts] buffer and one all-gather of the fp64
+distance partials, which are then added in rank order so that every rank computes the same
+distortion bit for bit.  Integer sums make the n-GPU codebook identical to the 1-GPU one.
+"""
+import math
+
+import torch
+
+
+class LBGResult:
+    def __init__(self, codebook, iters_per_stage, converged_iter, distortions):
+        self.codebook = codebook                  # (K, d) float64 tensor on the engine's device
+        self.iters_per_stage = iters_per_stage    # iterations run in each split stage
+        self.converged_iter = converged_iter      # the `i` the reference prints, or -1
+        self.distortions = distortions            # every iteration's distortion, in order
+
+
+def _group_size(group):
+    import torch.distributed as dist
+    return dist.get_world_size(group=group)
+
+
+def _allreduce_sum_(t, group):
+    import torch.distributed as dist
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def _ordered_sum(value, group):
+    """Sum of one fp64 scalar per rank, added in rank order on every rank."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group=group)
+    gathered = [torch.empty_like(value) for _ in range(world)]
+    dist.all_gather(gathered, value, group=group)
+    total = 0.0
+    for g in torch.stack(gathered).reshape(-1).cpu().tolist():
+        total += g
+    return total
+
+
+def initial_centroid(engine, blocks, group=None):
+    """np.mean(self.blocks, axis=0) of VQ_Full.py:67 as exact integer column sums / N."""
+    sums = engine.colsum(blocks)
+    n = torch.tensor([blocks.shape[0]], dtype=torch.int64, device=sums.device)
+    packed = torch.cat([sums, n])            # laid out as a one-cluster [sums | count] buffer
+    if group is not None:
+        _allreduce_sum_(packed, group)
+    n_total = int(packed[-1].item())
+    if n_total == 0:
+        raise ValueError("no block vectors")
+    # one IEEE divide of an exactly representable integer by the count, as numpy does
+    d = sums.numel()
+    centroid = engine.lbg_finalize(packed, torch.zeros((1, d), dtype=torch.float64, device=sums.device))
+    return centroid, n_total
+
+
+def lbg_iteration(engine, blocks, cb, n_total, group=None):
+    """One pass of VQ_Full.py:77-90.  Returns (new codebook, distortion as a Python float)."""
+    acc, dist = engine.lbg_accum(blocks, cb)
+    if group is not None:
+        _allreduce_sum_(acc, group)
+        total = _ordered_sum(dist, group)
+    else:
+        total = float(dist.item())
+    new_cb = engine.lbg_finalize(acc, cb)
+    return new_cb, total / float(n_total)
+
+
+def train_lbg(engine, blocks, k, epsilon=0.01, threshold=0.001, max_iterations=100, group=None, log=print,
+              iters_per_stage=None):
+    """Follows VQ_Full.py:60-98.
+
+    blocks: this rank's (N_local, d) uint8 shard on the engine's device.  group: a
+    torch.distributed process group when the vectors are sharded (None = single GPU).
+    iters_per_stage: optional list forcing the number of iterations of each stage (parity runs
+    "given the same iteration count"); the stop rule is then not consulted.
+    """
+    centroid, n_total = initial_centroid(engine, blocks, group)
+    if k > n_total:
+        raise ValueError(
+            f"Invalid quantization level k={k}: cannot exceed the total number of image blocks ({n_total})."
+        )
+    cb = centroid
+    iters, conv, distortions = [], [], []
+    stage = 0
+    while cb.shape[0] < k:
+        cb = engine.lbg_split(cb, epsilon)
+        prev = float("inf")
+        done, conv_i = 0, -1
+        forced = None if iters_per_stage is None else int(iters_per_stage[stage])
+        limit = max_iterations if forced is None else forced
+        for i in range(limit):
+            cb, distortion = lbg_iteration(engine, blocks, cb, n_total, group)
+            distortions.append(distortion)
+            done += 1
+            if forced is None and prev != float("inf"):
+                # prev == 0 gives nan (or inf), which never satisfies the test -- as in the reference
+                change = abs(prev - distortion) / prev if prev != 0.0 else float("nan")
+                if change < threshold:
+                    conv_i = i
+                    if log is not None:
+                        log(f"Converged at iter {i}, distortion={distortion:.3f}")
+                    break
+            prev = distortion
+        iters.append(done)
+        conv.append(conv_i)
+        stage += 1
+    return LBGResult(cb, iters, conv, distortions)
+
+
+def final_codebook_size(k):
+    """Codebook size the doubling loop of VQ_Full.py:70 ends with: the next power of two >= k."""
+    return 1 if k <= 1 else 1 << math.ceil(math.log2(k))
