@@ -46,9 +46,10 @@ int vq_abi_version(void);
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char *vq_last_error(void);
 
-/* Bytes of device scratch that vq_encode_l1 / vq_lbg_accum / vq_decode_u8 need for a (K, d)
- * codebook.  Pure host arithmetic. */
-size_t vq_workspace_bytes(int K, int d);
+/* Bytes of device scratch for a (K, d) codebook.  N is the number of block vectors of the
+ * vq_lbg_accum call the workspace is for (it sizes the per-chunk distance sums); pass N = 0 for
+ * vq_encode_l1, vq_codebook_prepare / vq_encode_l1_prepared and vq_decode_u8.  Pure host arithmetic. */
+size_t vq_workspace_bytes(int K, int d, int64_t N);
 
 /* Block extraction.  Replaces Codebook.__init__'s padding (VQ_Full.py:23-33) and
  * Codebook.image_to_blocks (VQ_Full.py:51-57): img is (H, W, C) uint8, padded on the bottom /
@@ -63,19 +64,40 @@ int vq_colsum_u8(const uint8_t *blocks, int64_t N, int d, uint64_t *sums, void *
 
 /* Nearest codeword.  Replaces cdist(..., 'cityblock') + np.argmin of Codebook.compress
  * (VQ_Full.py:124-125): labels[n] = argmin_k sum_e |double(blocks[n,e]) - cb[k,e]| with the sum
- * taken left to right in fp64 and the lowest k winning ties.  min_dist (nullable) receives the
- * winning fp64 distance per vector (the values VQ_Full.py:89 gathers). */
+ * taken left to right in fp64 and the lowest k winning ties.  labels holds N int32.  min_dist
+ * (nullable, N doubles) receives the winning fp64 distance per vector (the values VQ_Full.py:89
+ * gathers). */
 int vq_encode_l1(const uint8_t *blocks, int64_t N, int d, const double *cb, int K,
                  int32_t *labels, double *min_dist, int mode, void *ws, size_t ws_bytes, void *stream);
 
+/* The same search split in two, for callers that encode many batches with one codebook (a batch of
+ * images, repeated benchmark steps): vq_codebook_prepare fills ws from cb once (one small launch),
+ * vq_encode_l1_prepared then runs VQ_MODE_FAST's two kernels (filter, fp64 fix-up) per batch.  ws must not
+ * be handed to any other call in between; cb must still hold the same codebook.  Only dimensions
+ * d <= 192 (the SAD filter kernels) are served; others return VQ_E_UNSUPPORTED. */
+int vq_codebook_prepare(const double *cb, int K, int d, void *ws, size_t ws_bytes, void *stream);
+int vq_encode_l1_prepared(const uint8_t *blocks, int64_t N, int d, const double *cb, int K,
+                          int32_t *labels, double *min_dist, void *ws, size_t ws_bytes, void *stream);
+
 /* One LBG assignment pass, fused.  Replaces VQ_Full.py:77-90 up to the division: assigns every
- * vector as vq_encode_l1 does, then ADDS into sums[k*d+e] the byte sums of cluster k, into
- * counts[k] its member count, and OVERWRITES dist_sum[0] with the fp64 sum of the winning
- * distances (distortion = dist_sum / N).  sums and counts are accumulated into, so the caller
- * zeroes them first (and may all-reduce them across GPUs afterwards).  labels is nullable. */
+ * vector as vq_encode_l1 does (labels: N int32, min_dist: N doubles, both overwritten), ADDS into
+ * sums[k*d+e] the byte sums of cluster k and into counts[k] its member count, and OVERWRITES
+ * dist_sum[0] with the sum of min_dist taken in numpy's order (see vq_numpy_sum_f64), so that
+ * dist_sum / N is bit for bit the np.mean of VQ_Full.py:90.  sums and counts are accumulated
+ * into, so the caller zeroes them first (and may all-reduce them across GPUs afterwards).
+ * chunk_sums (nullable) receives the ceil(N / 8192) per-chunk sums dist_sum is the left-to-right
+ * total of; ranks that hold consecutive, 8192-aligned shards can concatenate them to reproduce
+ * the single-process value. */
 int vq_lbg_accum(const uint8_t *blocks, int64_t N, int d, const double *cb, int K,
-                 uint64_t *sums, uint64_t *counts, double *dist_sum, int32_t *labels, int mode,
-                 void *ws, size_t ws_bytes, void *stream);
+                 uint64_t *sums, uint64_t *counts, int32_t *labels, double *min_dist, double *dist_sum,
+                 double *chunk_sums, int mode, void *ws, size_t ws_bytes, void *stream);
+
+/* Sum of an fp64 vector in the order numpy.add.reduce uses on a contiguous array (what np.mean
+ * does before dividing, VQ_Full.py:90): pairwise summation -- runs of up to 128 elements with
+ * eight interleaved partial sums, halved recursively -- inside chunks of 8192 elements, the chunk
+ * results added left to right.  out[0] receives the sum, chunk_sums (ceil(N / 8192) + 1 doubles,
+ * required) the per-chunk sums. */
+int vq_numpy_sum_f64(const double *v, int64_t N, double *out, double *chunk_sums, void *stream);
 
 /* Per-cluster byte sums and counts for a given labelling (the inputs of np.mean(members, axis=0),
  * VQ_Full.py:82-84).  Accumulates into sums / counts like vq_lbg_accum. */

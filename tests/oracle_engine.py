@@ -29,21 +29,25 @@ class OracleEngine:
             return torch.from_numpy(labels), torch.from_numpy(mind)
         return torch.from_numpy(labels)
 
-    def lbg_accum(self, blocks, cb, want_labels=False, mode=None):
+    def lbg_accum(self, blocks, cb, want_labels=False, mode=None, want_chunks=False):
         b = blocks.numpy()
         K, d = cb.shape
-        if b.shape[0] == 0:
+        N = b.shape[0]
+        if N == 0:
             acc = torch.zeros(K * d + K, dtype=torch.int64)
-            dist = torch.zeros(1, dtype=torch.float64)
-            return (acc, dist, torch.zeros(0, dtype=torch.int32)) if want_labels else (acc, dist)
-        labels, mind = o.encode_l1(b, cb.numpy(), want_dist=True)
-        sums, counts = o.accumulate(b, labels, K)
-        acc = torch.from_numpy(np.concatenate([sums.reshape(-1), counts]).astype(np.int64))
-        total = 0.0
-        for v in mind.tolist():          # plain left-to-right sum of the exact distances
-            total += v
-        dist = torch.tensor([total], dtype=torch.float64)
-        return (acc, dist, torch.from_numpy(labels)) if want_labels else (acc, dist)
+            labels, mind = np.zeros(0, dtype=np.int32), np.zeros(0)
+        else:
+            labels, mind = o.encode_l1(b, cb.numpy(), want_dist=True)
+            sums, counts = o.accumulate(b, labels, K)
+            acc = torch.from_numpy(np.concatenate([sums.reshape(-1), counts]).astype(np.int64))
+        dist = torch.tensor([o.numpy_sum(mind)], dtype=torch.float64)
+        out = [acc, dist]
+        if want_labels:
+            out.append(torch.from_numpy(labels))
+        if want_chunks:
+            out.append(torch.tensor([o.pairwise_sum(mind[lo:lo + 8192]) for lo in range(0, N, 8192)],
+                                    dtype=torch.float64))
+        return tuple(out)
 
     def lbg_finalize(self, acc, cb_old):
         K, d = cb_old.shape

@@ -36,8 +36,9 @@ def test_host_only_entry_points():
     """Pure host arithmetic (no GPU work): workspace and packed sizes, argument validation."""
     from vector_quantization_amd import _lib
     lib = _lib.lib
-    assert lib.vq_workspace_bytes(256, 16) >= 256 * 16 * 8 + 256 * 16 * 2
-    assert lib.vq_workspace_bytes(0, 16) == 0
+    assert lib.vq_workspace_bytes(256, 16, 0) >= 256 * 16 * 8 + 256 * 16 * 2
+    assert lib.vq_workspace_bytes(256, 16, 1 << 30) >= lib.vq_workspace_bytes(256, 16, 0) + (1 << 30) // 8192 * 8
+    assert lib.vq_workspace_bytes(0, 16, 0) == 0
     assert lib.vq_packed_bytes(1000, 256) == 1000
     assert lib.vq_packed_bytes(1000, 5) == (1000 * 3 + 7) // 8
     assert lib.vq_packed_bytes(1000, 1) == 0

@@ -43,12 +43,14 @@ def _worker(rank, world, port, case, splits, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case,frac", [("man_2x2_k5", 0.5), ("synth_iid_128_4x4_k32", 0.3), ("luffy_2x2_k16", 0.0)])
+@pytest.mark.parametrize("case,frac", [("man_2x2_k5", 0.5), ("synth_iid_128_4x4_k32", 0.3), ("luffy_2x2_k16", 0.0),
+                                       ("luffy_2x2_k16", -8192)])
 def test_sharded_training_equals_single_process(tmp_path, case, frac):
     from vqtest_util import load_golden
     g = load_golden(case)
     N = g["blocks"].shape[0]
-    cut = int(N * frac)                      # frac 0.0: rank 0 holds no vectors at all
+    # frac 0.0: rank 0 holds no vectors at all; negative: an absolute, 8192-aligned cut
+    cut = -frac if frac < 0 else int(N * frac)
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), case, [0, cut, N], str(tmp_path)), nprocs=world, join=True)
     r0 = np.load(tmp_path / "rank0.npz")
@@ -58,3 +60,7 @@ def test_sharded_training_equals_single_process(tmp_path, case, frac):
     assert np.array_equal(r0["codebook"], g["codebook"])             # and it is the reference's, bit for bit
     assert list(r0["iters"]) == list(g["iters_per_stage"])
     assert np.allclose(r0["dist"], g["distortions"], rtol=1e-12, atol=0)
+    if cut % 8192 == 0:
+        # shards that keep numpy's 8192-element summation chunks intact reproduce the reference's
+        # distortion values bit for bit
+        assert np.array_equal(r0["dist"], g["distortions"])

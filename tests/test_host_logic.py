@@ -42,6 +42,7 @@ def test_codebook_class_end_to_end(tmp_path, train_case, engine, capsys):
     assert isinstance(final, list) and isinstance(final[0][0][0][0], float)
     assert np.array(final).shape == (len(g["codebook"]), int(g["bh"]), int(g["bw"]), C)
     assert cb.training.iters_per_stage == list(g["iters_per_stage"])
+    assert np.array_equal(np.array(cb.training.distortions), g["distortions"])      # numpy-order mean, bit for bit
 
     labels = cb.compress()
     assert labels.dtype == np.int64 and labels.shape == g["labels"].shape

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Profiling target: BASELINE config 2's kernels only (no host baseline, few launches).
+Run under rocprofv3 --kernel-trace / --pmc.  Usage: python3 tools/prof_encode.py [reps]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import structured_image  # noqa: E402
+from vector_quantization_amd import HipEngine, train_lbg  # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+dev = torch.device("cuda:0")
+eng = HipEngine(dev)
+img = structured_image(8192, 8192, 1000, dev)
+blocks = eng.blocks_from_image(img, 4, 4)
+crop = eng.blocks_from_image(structured_image(2048, 2048, 0, dev), 4, 4)
+cb = train_lbg(eng, crop, 256, log=None).codebook
+prepared = eng.prepare_codebook(cb)
+labels = torch.empty(blocks.shape[0], dtype=torch.int32, device=dev)
+torch.cuda.synchronize()
+for _ in range(reps):
+    eng.encode_prepared(blocks, prepared, labels=labels)
+for _ in range(reps):
+    eng.decode(labels.view(2048, 2048), cb, 4, 4, 1)
+for _ in range(reps):
+    eng.lbg_accum(blocks, cb)
+for _ in range(reps):
+    eng.blocks_from_image(img, 4, 4)
+torch.cuda.synchronize()
+print("done")

@@ -32,11 +32,14 @@ _dbl = ctypes.c_double
 SIGNATURES = {
     "vq_abi_version": (_i, []),
     "vq_last_error": (ctypes.c_char_p, []),
-    "vq_workspace_bytes": (_sz, [_i, _i]),
+    "vq_workspace_bytes": (_sz, [_i, _i, _i64]),
     "vq_blocks_u8": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "vq_colsum_u8": (_i, [_vp, _i64, _i, _vp, _vp]),
     "vq_encode_l1": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp]),
-    "vq_lbg_accum": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "vq_codebook_prepare": (_i, [_vp, _i, _i, _vp, _sz, _vp]),
+    "vq_encode_l1_prepared": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "vq_lbg_accum": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "vq_numpy_sum_f64": (_i, [_vp, _i64, _vp, _vp, _vp]),
     "vq_accum_labels": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp, _vp]),
     "vq_lbg_finalize": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "vq_lbg_split": (_i, [_vp, _i, _i, _dbl, _vp, _vp]),

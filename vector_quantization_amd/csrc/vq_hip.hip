@@ -12,13 +12,18 @@
 //      |T_k - S_k| <= E_k = sum_e |c_e * 2^s - C_e|, and the kernel knows Emax >= every E_k.
 //      Each lane tracks the two smallest keys (S_k << kbits | k); when S_second - S_first >
 //      2 * Emax the first key's codeword is the unique fp64 argmin and no fp64 work is needed.
-//   2. Re-check.  Otherwise the whole wave evaluates that vector against every codeword in
-//      sequential fp64 (lanes <-> codewords, coalesced reads of a transposed fp64 codebook) and
-//      reduces (distance, index) lexicographically, which is numpy's first-minimum rule.
+//   2. Re-check.  Otherwise the vector's label is stored negative, and a second kernel lets one
+//      whole wave evaluate that vector against every codeword in sequential fp64 (lanes <->
+//      codewords, coalesced reads of a transposed fp64 codebook), reducing (distance, index)
+//      lexicographically, which is numpy's first-minimum rule.
 //   A codeword whose row is bit-identical to an earlier row can never win (ties go to the lower
 //   index), so the filter gives it a key that never competes; duplicated codewords (the twin that
 //   the split of an all-zero centroid produces) therefore do not force re-checks.
 // EXACT mode evaluates every distance in sequential fp64 and is the on-device cross-check.
+//
+// Distortion.  The per-vector winning distances go to an array, and their sum is taken in the
+// order numpy.mean uses (VQ_Full.py:90): pairwise summation inside 8192-element chunks, chunk sums
+// added left to right.  The stop rule of the training loop therefore sees the reference's value.
 //
 // No entry point allocates memory; scratch comes in through the workspace argument.
 #include <hip/hip_runtime.h>
@@ -59,6 +64,7 @@ int fail(int code, const char *fmt, ...) {
 constexpr int ABI_VERSION = 1;
 constexpr int WAVE = 64;
 constexpr int MAX_GRID = 4096;          // upper bound on workgroups of the assignment kernels
+constexpr int64_t NP_CHUNK = 8192;      // numpy's reduction buffer: elements per pairwise-summed chunk
 constexpr int MAX_D_FAST = 192;         // largest vector dimension of the SAD filter kernels
 constexpr int MAX_K = 1 << 20;
 
@@ -71,13 +77,13 @@ struct WsLayout {
     size_t bias;       // K uint32: key bias (index, plus the never-wins bit for duplicate rows)
     size_t cbT;        // d * K doubles: transposed fp64 codebook
     size_t cb_u8;      // K * d bytes: codebook truncated to uint8 (decode)
-    size_t partials;   // MAX_GRID doubles: per-workgroup distance sums
+    size_t chunks;     // ceil(N / 8192) + 1 doubles: per-chunk sums of the distance array
     size_t total;
 };
 
 int dp2_bucket(int d);   // forward
 
-WsLayout ws_layout(int K, int d) {
+WsLayout ws_layout(int K, int d, int64_t N) {
     WsLayout L;
     int dp2 = dp2_bucket(d);
     if (dp2 <= 0) dp2 = (d + 1) / 2;
@@ -87,7 +93,7 @@ WsLayout ws_layout(int K, int d) {
     L.bias = off;     off += align_up((size_t)K * 4, 256);
     L.cbT = off;      off += align_up((size_t)K * d * 8, 256);
     L.cb_u8 = off;    off += align_up((size_t)K * d, 256);
-    L.partials = off; off += align_up((size_t)MAX_GRID * 8, 256);
+    L.chunks = off;   off += align_up((size_t)((N + NP_CHUNK - 1) / NP_CHUNK + 1) * 8, 256);
     L.total = off;
     return L;
 }
@@ -252,9 +258,19 @@ __global__ __launch_bounds__(256) void k_finalize(const unsigned long long *__re
 // ------------------------------------------------------------------------------------------------
 // codebook preparation for the SAD filter (one workgroup)
 // ------------------------------------------------------------------------------------------------
+constexpr int PREP_HASH_CAP = 8192;     // codebooks up to this size get the duplicate-row scan
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long h, unsigned long long v) {
+    h ^= v;
+    h *= 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+    return h;
+}
+
 __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb, int K, int d, int dp2,
                                                   PrepHeader *__restrict__ hdr, uint32_t *__restrict__ c16,
                                                   uint32_t *__restrict__ bias, double *__restrict__ cbT) {
+    extern __shared__ __align__(16) unsigned long long s_hash[];   // min(K, PREP_HASH_CAP) row hashes
     __shared__ uint32_t s_cmax;
     __shared__ uint32_t s_emax;
     if (threadIdx.x == 0) {
@@ -279,15 +295,17 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
     int s = 8;
     while (s > 0 && ((uint64_t)cmax << s) > 65535ull) --s;
     const double scale = (double)(1u << s);
-    // phase B: one thread per codeword
+    const bool scan_dups = K <= PREP_HASH_CAP;
+    // phase B: one thread per codeword: fixed-point row, rounding-error bound, transposed copy, row hash
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
         const double *row = cb + (size_t)k * d;
         double err = 0.0;
+        unsigned long long h = 0x243F6A8885A308D3ull;
         for (int p = 0; p < dp2; ++p) {
             uint32_t pair = 0;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                int e = 2 * p + h;
+            for (int hh = 0; hh < 2; ++hh) {
+                int e = 2 * p + hh;
                 if (e < d) {
                     double c = row[e];
                     double t = c * scale;
@@ -297,8 +315,9 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
                     double de = fabs(t - q);
                     if (!(de == de)) de = 4.0e9;
                     err += de;
-                    pair |= ((uint32_t)q) << (16 * h);
+                    pair |= ((uint32_t)q) << (16 * hh);
                     cbT[(size_t)e * K + k] = c;
+                    h = mix64(h, (unsigned long long)__double_as_longlong(c));
                 }
             }
             c16[(size_t)k * dp2 + p] = pair;
@@ -306,19 +325,30 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
         // strict integer upper bound of err (plus slack for the fp64 rounding of err itself)
         uint32_t ek = (err < 2.0e9) ? (uint32_t)err + 2u : 0x7fffffffu;
         atomicMax(&s_emax, ek);
-        // duplicate of an earlier row?  (bitwise comparison: identical rows give identical distances)
+        if (scan_dups) s_hash[k] = h;
+    }
+    __syncthreads();
+    // phase C: is row k bit-identical to an earlier row?  Hashes are compared in LDS; the rows
+    // themselves only on a hash match.  Identical rows give identical distances, so the later one
+    // can never win and gets the never-competes bit.
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
         uint32_t dup = 0;
-        const unsigned long long *rowb = reinterpret_cast<const unsigned long long *>(row);
-        for (int j = 0; j < k && !dup; ++j) {
-            const unsigned long long *rj = reinterpret_cast<const unsigned long long *>(cb + (size_t)j * d);
-            if (rj[0] != rowb[0]) continue;
-            int e = 1;
-            while (e < d && rj[e] == rowb[e]) ++e;
-            if (e == d) dup = 1;
+        if (scan_dups) {
+            const unsigned long long hk = s_hash[k];
+            const unsigned long long *rowb = reinterpret_cast<const unsigned long long *>(cb + (size_t)k * d);
+            for (int j = 0; j < k; ++j) {
+                if (s_hash[j] != hk) continue;
+                const unsigned long long *rj = reinterpret_cast<const unsigned long long *>(cb + (size_t)j * d);
+                int e = 0;
+                while (e < d && rj[e] == rowb[e]) ++e;
+                if (e == d) {
+                    dup = 1;
+                    break;
+                }
+            }
         }
         bias[k] = (uint32_t)k | (dup << 31);
     }
-    __syncthreads();
     if (threadIdx.x == 0) {
         hdr->shift = (uint32_t)s;
         hdr->emax = s_emax;
@@ -345,14 +375,10 @@ struct AssignArgs {
     int K;
     int kbits;
     const PrepHeader *hdr;
-    const uint32_t *c16;
-    const uint32_t *bias;
-    const double *cbT;
-    int32_t *labels;            // nullable
-    double *min_dist;           // nullable
+    int32_t *labels;            // N; a vector whose filter result is ambiguous gets -1 - (filter's index)
+    double *min_dist;           // nullable; written for unambiguous vectors only
     unsigned long long *sums;   // ACC_*: (K, d)
     unsigned long long *counts; // ACC_*: (K)
-    double *partials;           // ACC_*: per-workgroup distance sums
     int acc_mode;
     int vec4;                   // rows may be read as aligned 32-bit words (d % 4 == 0, base 4-byte aligned)
     int64_t ntiles;
@@ -361,14 +387,13 @@ struct AssignArgs {
 template <int DP2, int R, int KEYMODE>
 __global__ __launch_bounds__(512) void k_assign_fast(const AssignArgs a, const uint32_t *__restrict__ c16,
                                                      const uint32_t *__restrict__ bias) {
-    extern __shared__ __align__(16) uint32_t s_tab[];   // ACC_LDS: K * (d + 1) sums|count; then 16 doubles for the reduction
+    extern __shared__ __align__(16) uint32_t s_tab[];   // ACC_LDS: K * (d + 1) words, [sums | count] per codeword
     const int tid = threadIdx.x;
-    const int lane = tid & (WAVE - 1);
     const int BLOCK = blockDim.x;
     const int d = a.d, K = a.K;
     const int acc_mode = a.acc_mode;
     const int tabn = K * (d + 1);
-    const bool want_dist = (a.min_dist != nullptr) || (acc_mode != ACC_NONE);
+    const bool want_dist = a.min_dist != nullptr;
 
     if (acc_mode == ACC_LDS) {
         for (int i = tid; i < tabn; i += BLOCK) s_tab[i] = 0u;
@@ -383,7 +408,6 @@ __global__ __launch_bounds__(512) void k_assign_fast(const AssignArgs a, const u
     // bias as its single scalar operand (one instruction instead of shift + add).
     uint32_t kbits_v = kbits;
     asm volatile("" : "+v"(kbits_v));
-    double dsum = 0.0;
     int tiles_done = 0;
 
     for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
@@ -467,11 +491,11 @@ __global__ __launch_bounds__(512) void k_assign_fast(const AssignArgs a, const u
             for (int p = 0; p < DP2; ++p) cw[p] = c16[(size_t)k * DP2 + p];
             step(cw, bias[k], k);
         }
-        // ---- resolve, measure, write, accumulate ----
+        // ---- decide, measure, write, accumulate ----
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int64_t n = base + (int64_t)r * BLOCK + tid;
-            const bool valid = n < a.N;
+            if (n >= a.N) continue;
             uint32_t s1, s2;
             int idx;
             if (KEYMODE == KEY_PACKED) {
@@ -483,24 +507,12 @@ __global__ __launch_bounds__(512) void k_assign_fast(const AssignArgs a, const u
                 s1 = m1[r];
                 s2 = m2[r];
             }
-            bool amb = valid && (s2 - s1 <= window);
-            double dist = 0.0;
-            bool have_dist = false;
-            unsigned long long mask = __ballot(amb);
-            while (mask) {
-                int src = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                int64_t nsrc = base + (int64_t)r * BLOCK + (tid - lane + src);   // wave-uniform
-                int ri;
-                double rd;
-                exact_search_wave(a.blocks + (size_t)nsrc * d, d, a.cbT, K, lane, ri, rd);
-                if (lane == src) {
-                    idx = ri;
-                    dist = rd;
-                    have_dist = true;
-                }
+            if (s2 - s1 <= window) {
+                a.labels[n] = -1 - idx;                 // near-tie: the fix-up kernel decides in fp64
+                continue;
             }
-            if (valid && want_dist && !have_dist) {
+            a.labels[n] = idx;
+            if (want_dist) {
                 const double *crow = a.cb + (size_t)idx * d;
                 double acc = 0.0;
 #pragma unroll
@@ -514,35 +526,30 @@ __global__ __launch_bounds__(512) void k_assign_fast(const AssignArgs a, const u
                         }
                     }
                 }
-                dist = acc;
+                a.min_dist[n] = acc;
             }
-            if (valid) {
-                if (a.labels) a.labels[n] = idx;
-                if (a.min_dist) a.min_dist[n] = dist;
-                if (acc_mode != ACC_NONE) dsum += dist;
-                if (acc_mode == ACC_LDS) {
-                    uint32_t *t = s_tab + (size_t)idx * (d + 1);
+            if (acc_mode == ACC_LDS) {
+                uint32_t *t = s_tab + (size_t)idx * (d + 1);
 #pragma unroll
-                    for (int p = 0; p < DP2; ++p) {
+                for (int p = 0; p < DP2; ++p) {
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            int e = 2 * p + h;
-                            if (e < d) atomicAdd(&t[e], (x[r][p] >> (s + 16 * h)) & 0xffu);
-                        }
+                    for (int h = 0; h < 2; ++h) {
+                        int e = 2 * p + h;
+                        if (e < d) atomicAdd(&t[e], (x[r][p] >> (s + 16 * h)) & 0xffu);
                     }
-                    atomicAdd(&t[d], 1u);
-                } else if (acc_mode == ACC_GLOBAL) {
-                    unsigned long long *t = a.sums + (size_t)idx * d;
-#pragma unroll
-                    for (int p = 0; p < DP2; ++p) {
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            int e = 2 * p + h;
-                            if (e < d) atomicAdd(&t[e], (unsigned long long)((x[r][p] >> (s + 16 * h)) & 0xffu));
-                        }
-                    }
-                    atomicAdd(&a.counts[idx], 1ull);
                 }
+                atomicAdd(&t[d], 1u);
+            } else if (acc_mode == ACC_GLOBAL) {
+                unsigned long long *t = a.sums + (size_t)idx * d;
+#pragma unroll
+                for (int p = 0; p < DP2; ++p) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        int e = 2 * p + h;
+                        if (e < d) atomicAdd(&t[e], (unsigned long long)((x[r][p] >> (s + 16 * h)) & 0xffu));
+                    }
+                }
+                atomicAdd(&a.counts[idx], 1ull);
             }
         }
         // 32-bit LDS sums hold 255 * (vectors per workgroup): flush long before they can wrap
@@ -551,9 +558,9 @@ __global__ __launch_bounds__(512) void k_assign_fast(const AssignArgs a, const u
             for (int i = tid; i < tabn; i += BLOCK) {
                 uint32_t v = s_tab[i];
                 if (v) {
-                    int k = i / (d + 1), e = i - k * (d + 1);
-                    if (e < d) atomicAdd(&a.sums[(size_t)k * d + e], (unsigned long long)v);
-                    else atomicAdd(&a.counts[k], (unsigned long long)v);
+                    int kk = i / (d + 1), e = i - kk * (d + 1);
+                    if (e < d) atomicAdd(&a.sums[(size_t)kk * d + e], (unsigned long long)v);
+                    else atomicAdd(&a.counts[kk], (unsigned long long)v);
                     s_tab[i] = 0u;
                 }
             }
@@ -561,40 +568,176 @@ __global__ __launch_bounds__(512) void k_assign_fast(const AssignArgs a, const u
         }
     }
 
-    if (acc_mode != ACC_NONE) {
+    if (acc_mode == ACC_LDS) {
         __syncthreads();
-        if (acc_mode == ACC_LDS) {
-            for (int i = tid; i < tabn; i += BLOCK) {
-                uint32_t v = s_tab[i];
-                if (v) {
-                    int k = i / (d + 1), e = i - k * (d + 1);
-                    if (e < d) atomicAdd(&a.sums[(size_t)k * d + e], (unsigned long long)v);
-                    else atomicAdd(&a.counts[k], (unsigned long long)v);
-                }
+        for (int i = tid; i < tabn; i += BLOCK) {
+            uint32_t v = s_tab[i];
+            if (v) {
+                int kk = i / (d + 1), e = i - kk * (d + 1);
+                if (e < d) atomicAdd(&a.sums[(size_t)kk * d + e], (unsigned long long)v);
+                else atomicAdd(&a.counts[kk], (unsigned long long)v);
             }
-            __syncthreads();
-        }
-        // fixed-order reduction of the distance sums: xor tree inside a wave, then waves in order
-        double *s_red = reinterpret_cast<double *>(s_tab);
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) dsum += __shfl_xor(dsum, off, WAVE);
-        if (lane == 0) s_red[tid >> 6] = dsum;
-        __syncthreads();
-        if (tid == 0) {
-            double t = 0.0;
-            for (int w = 0; w < (BLOCK >> 6); ++w) t += s_red[w];
-            a.partials[blockIdx.x] = t;
         }
     }
 }
 
-// Sum of the per-workgroup distance partials in index order (deterministic).
-__global__ void k_sum_partials(const double *__restrict__ partials, int n, double *__restrict__ out) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        double t = 0.0;
-        for (int i = 0; i < n; ++i) t += partials[i];
-        out[0] = t;
+// Fix-up pass of FAST mode: every vector whose label is negative is searched again by a whole
+// wave in sequential fp64 (exact_search_wave); its final label, its distance and -- when sums is
+// non-null -- its contribution to the cluster sums are written here.  One wave scans 64 labels
+// per trip; the result does not depend on how vectors are spread over waves.
+__global__ __launch_bounds__(256) void k_fixup(const uint8_t *__restrict__ blocks, int64_t N, int d,
+                                               const double *__restrict__ cbT, int K, int32_t *__restrict__ labels,
+                                               double *__restrict__ min_dist, unsigned long long *__restrict__ sums,
+                                               unsigned long long *__restrict__ counts) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t ngroups = (N + WAVE - 1) / WAVE;
+    for (int64_t g = wave; g < ngroups; g += nwaves) {
+        const int64_t n = g * WAVE + lane;
+        const int lab = n < N ? labels[n] : 0;
+        unsigned long long mask = __ballot(lab < 0);
+        while (mask) {
+            const int src = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const int64_t nsrc = g * WAVE + src;              // wave-uniform
+            const uint8_t *xrow = blocks + (size_t)nsrc * d;
+            int ri;
+            double rd;
+            exact_search_wave(xrow, d, cbT, K, lane, ri, rd);
+            if (lane == src) {
+                labels[n] = ri;
+                if (min_dist) min_dist[n] = rd;
+            }
+            if (sums) {
+                for (int e = lane; e < d; e += WAVE) {
+                    unsigned v = xrow[e];
+                    if (v) atomicAdd(&sums[(size_t)ri * d + e], (unsigned long long)v);
+                }
+                if (lane == 0) atomicAdd(&counts[ri], 1ull);
+            }
+        }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// numpy-order sum of an fp64 vector (the np.mean of VQ_Full.py:90 before its division)
+// ------------------------------------------------------------------------------------------------
+// numpy's pairwise routine on one run of n <= 128 elements.
+__device__ __forceinline__ double np_leaf_sum(const double *__restrict__ a, int n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
+// One wave per full 8192-element chunk: lane l sums leaf l (128 elements) as numpy's unrolled
+// loop does; the recursive halving above the leaves is a balanced binary tree over adjacent
+// leaves, i.e. the xor-shuffle tree.  chunk_sums[c] receives the chunk's pairwise sum.
+__global__ __launch_bounds__(256) void k_npsum_chunks(const double *__restrict__ v, int64_t nfull,
+                                                      double *__restrict__ chunk_sums) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t c = wave; c < nfull; c += nwaves) {
+        double t = np_leaf_sum(v + c * NP_CHUNK + (int64_t)lane * 128, 128);
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) t += __shfl_xor(t, off, WAVE);
+        if (lane == 0) chunk_sums[c] = t;
+    }
+}
+
+// One workgroup: the trailing partial chunk (m = N mod 8192 elements, numpy's uneven recursive
+// halving reproduced with an explicit stack), then the left-to-right sum over all chunk sums.
+__global__ __launch_bounds__(1024) void k_npsum_final(const double *__restrict__ v, int64_t N, int64_t nfull,
+                                                      double *__restrict__ chunk_sums, double *__restrict__ out) {
+    __shared__ int s_off[160], s_len[160];
+    __shared__ double s_leaf[160];
+    __shared__ int s_nleaf;
+    __shared__ double s_buf[1024];
+    __shared__ int s_sn[20], s_sstate[20];
+    __shared__ double s_sleft[20];
+    const int m = (int)(N - nfull * NP_CHUNK);
+    const double *tail = v + nfull * NP_CHUNK;
+    if (m > 0) {
+        if (threadIdx.x == 0) {
+            // leaves of the recursion, left to right
+            int sp = 0, cnt = 0;
+            s_sn[sp] = m; s_sstate[sp] = 0; ++sp;               // here s_sstate holds the run's offset
+            while (sp > 0) {
+                --sp;
+                int n = s_sn[sp], off = s_sstate[sp];
+                if (n <= 128) {
+                    s_off[cnt] = off; s_len[cnt] = n; ++cnt;
+                } else {
+                    int n2 = n / 2;
+                    n2 -= n2 % 8;
+                    s_sn[sp] = n - n2; s_sstate[sp] = off + n2; ++sp;   // right half: popped second
+                    s_sn[sp] = n2; s_sstate[sp] = off; ++sp;            // left half: popped first
+                }
+            }
+            s_nleaf = cnt;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < s_nleaf) s_leaf[threadIdx.x] = np_leaf_sum(tail + s_off[threadIdx.x], s_len[threadIdx.x]);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // evaluate pairwise(m) = pairwise(left) + pairwise(right) over the leaf sums
+            int sp = 0, next = 0;
+            double ret = 0.0;
+            s_sn[sp] = m; s_sstate[sp] = 0; ++sp;
+            while (sp > 0) {
+                const int f = sp - 1;
+                const int n = s_sn[f];
+                if (n <= 128) {
+                    ret = s_leaf[next++];
+                    --sp;
+                    continue;
+                }
+                int n2 = n / 2;
+                n2 -= n2 % 8;
+                if (s_sstate[f] == 0) {
+                    s_sstate[f] = 1;
+                    s_sn[sp] = n2; s_sstate[sp] = 0; ++sp;
+                } else if (s_sstate[f] == 1) {
+                    s_sleft[f] = ret;
+                    s_sstate[f] = 2;
+                    s_sn[sp] = n - n2; s_sstate[sp] = 0; ++sp;
+                } else {
+                    ret = s_sleft[f] + ret;
+                    --sp;
+                }
+            }
+            chunk_sums[nfull] = ret;
+        }
+        __syncthreads();
+    }
+    // left-to-right sum of the chunk sums, staged through LDS 1024 at a time
+    const int64_t nchunks = nfull + (m > 0 ? 1 : 0);
+    double total = 0.0;
+    for (int64_t lo = 0; lo < nchunks; lo += 1024) {
+        const int64_t i = lo + threadIdx.x;
+        s_buf[threadIdx.x] = i < nchunks ? chunk_sums[i] : 0.0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int cnt = (int)(nchunks - lo < 1024 ? nchunks - lo : 1024);
+            for (int j = 0; j < cnt; ++j) total += s_buf[j];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = total;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -604,10 +747,7 @@ __global__ __launch_bounds__(256) void k_assign_exact(const uint8_t *__restrict_
                                                       const double *__restrict__ cb, int K,
                                                       int32_t *__restrict__ labels, double *__restrict__ min_dist,
                                                       unsigned long long *__restrict__ sums,
-                                                      unsigned long long *__restrict__ counts,
-                                                      double *__restrict__ partials) {
-    __shared__ double s_red[4];
-    double dsum = 0.0;
+                                                      unsigned long long *__restrict__ counts) {
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
         const uint8_t *x = blocks + (size_t)n * d;
         double best = __builtin_huge_val();
@@ -624,7 +764,6 @@ __global__ __launch_bounds__(256) void k_assign_exact(const uint8_t *__restrict_
         if (labels) labels[n] = bidx;
         if (min_dist) min_dist[n] = best;
         if (sums) {
-            dsum += best;
             for (int e = 0; e < d; ++e) {
                 unsigned v = x[e];
                 if (v) atomicAdd(&sums[(size_t)bidx * d + e], (unsigned long long)v);
@@ -632,17 +771,10 @@ __global__ __launch_bounds__(256) void k_assign_exact(const uint8_t *__restrict_
             atomicAdd(&counts[bidx], 1ull);
         }
     }
-    if (partials) {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) dsum += __shfl_xor(dsum, off, WAVE);
-        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = dsum;
-        __syncthreads();
-        if (threadIdx.x == 0) partials[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-    }
 }
 
-// Per-cluster sums / counts for given labels: straight 64-bit atomics (used by EXACT mode and by
-// vq_accum_labels; not on the fast path).
+// Per-cluster sums / counts for given labels: straight 64-bit atomics (vq_accum_labels; not on the
+// fast path).
 __global__ __launch_bounds__(256) void k_accum_labels(const uint8_t *__restrict__ blocks, int64_t N, int d,
                                                       const int32_t *__restrict__ labels, int K,
                                                       unsigned long long *__restrict__ sums,
@@ -758,23 +890,25 @@ int grid_for(int64_t work_items, int block, int max_blocks) {
 }
 
 template <int DP2, int KEYMODE>
-int launch_assign_fast_t(const AssignArgs &a, int block, int grid, size_t lds, hipStream_t st) {
+int launch_assign_fast_t(const AssignArgs &a, const uint32_t *c16, const uint32_t *bias, int block, int grid,
+                         size_t lds, hipStream_t st) {
     constexpr int R = r_for(DP2);
     auto kern = k_assign_fast<DP2, R, KEYMODE>;
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, st, a, a.c16, a.bias);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, st, a, c16, bias);
     LAUNCH_CHECK("k_assign_fast");
     return VQ_OK;
 }
 
 template <int DP2>
-int launch_assign_fast_k(const AssignArgs &a, bool packed, int block, int grid, size_t lds, hipStream_t st) {
+int launch_assign_fast_k(const AssignArgs &a, const uint32_t *c16, const uint32_t *bias, bool packed, int block,
+                         int grid, size_t lds, hipStream_t st) {
     if constexpr (DP2 <= 32) {
-        if (packed) return launch_assign_fast_t<DP2, KEY_PACKED>(a, block, grid, lds, st);
+        if (packed) return launch_assign_fast_t<DP2, KEY_PACKED>(a, c16, bias, block, grid, lds, st);
     }
-    return launch_assign_fast_t<DP2, KEY_SPLIT>(a, block, grid, lds, st);
+    return launch_assign_fast_t<DP2, KEY_SPLIT>(a, c16, bias, block, grid, lds, st);
 }
 
 struct DeviceInfo {
@@ -800,21 +934,41 @@ int check_common(const void *blocks, int64_t N, int d, const void *cb, int K) {
     return VQ_OK;
 }
 
-// Runs the prepare kernel and the fused fast assignment.  acc_mode ACC_NONE -> encode only.
-int run_fast(const uint8_t *blocks, int64_t N, int d, const double *cb, int K, int32_t *labels, double *min_dist,
-             unsigned long long *sums, unsigned long long *counts, double *dist_sum, bool accumulate, void *ws,
-             hipStream_t st) {
+int check_ws(const void *ws, size_t ws_bytes, int K, int d, int64_t N) {
+    size_t need = ws_layout(K, d, N).total;
+    if (!ws || ws_bytes < need) return fail(VQ_E_WORKSPACE, "workspace of %zu bytes needed, %zu given", need, ws_bytes);
+    return VQ_OK;
+}
+
+bool fast_supported(int d) { return d <= MAX_D_FAST && dp2_bucket(d) > 0; }
+
+// Fills the workspace for a codebook: 16-bit fixed-point rows, key biases, transposed fp64 copy.
+int run_prepare(const double *cb, int K, int d, void *ws, hipStream_t st) {
     const int dp2 = dp2_bucket(d);
-    WsLayout L = ws_layout(K, d);
+    WsLayout L = ws_layout(K, d, 0);
+    char *w = static_cast<char *>(ws);
+    const size_t hash_lds = (size_t)(K <= PREP_HASH_CAP ? K : 1) * sizeof(unsigned long long);
+    if (hash_lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_prepare), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)hash_lds));
+    hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1024), hash_lds, st, cb, K, d, dp2, reinterpret_cast<PrepHeader *>(w + L.header),
+                       reinterpret_cast<uint32_t *>(w + L.c16), reinterpret_cast<uint32_t *>(w + L.bias),
+                       reinterpret_cast<double *>(w + L.cbT));
+    LAUNCH_CHECK("k_prepare");
+    return VQ_OK;
+}
+
+// FAST mode on a prepared workspace: the filter kernel, then the fp64 fix-up of the vectors it
+// marked.  sums == nullptr -> encode only.
+int run_fast(const uint8_t *blocks, int64_t N, int d, const double *cb, int K, int32_t *labels, double *min_dist,
+             unsigned long long *sums, unsigned long long *counts, void *ws, hipStream_t st) {
+    const int dp2 = dp2_bucket(d);
+    WsLayout L = ws_layout(K, d, 0);
     char *w = static_cast<char *>(ws);
     PrepHeader *hdr = reinterpret_cast<PrepHeader *>(w + L.header);
     uint32_t *c16 = reinterpret_cast<uint32_t *>(w + L.c16);
     uint32_t *bias = reinterpret_cast<uint32_t *>(w + L.bias);
     double *cbT = reinterpret_cast<double *>(w + L.cbT);
-    double *partials = reinterpret_cast<double *>(w + L.partials);
-
-    hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1024), 0, st, cb, K, d, dp2, hdr, c16, bias, cbT);
-    LAUNCH_CHECK("k_prepare");
 
     DeviceInfo di;
     int rc = device_info(di);
@@ -828,13 +982,11 @@ int run_fast(const uint8_t *blocks, int64_t N, int d, const double *cb, int K, i
     int acc_mode = ACC_NONE;
     size_t lds = 0;
     int block = 256;
-    if (accumulate) {
+    if (sums) {
         size_t tab = (size_t)K * (d + 1) * 4;
-        size_t tab_lds = tab < 128 ? 128 : tab;
-        if (tab_lds <= 40 * 1024) { acc_mode = ACC_LDS; lds = tab_lds; block = 256; }
-        else if (tab_lds <= 80 * 1024) { acc_mode = ACC_LDS; lds = tab_lds; block = 512; }
-        else if (tab_lds <= di.lds_per_block) { acc_mode = ACC_LDS; lds = tab_lds; block = 512; }
-        else { acc_mode = ACC_GLOBAL; lds = 128; }
+        if (tab <= 40 * 1024) { acc_mode = ACC_LDS; lds = tab; block = 256; }
+        else if (tab <= di.lds_per_block) { acc_mode = ACC_LDS; lds = tab; block = 512; }
+        else { acc_mode = ACC_GLOBAL; }
     }
     const int R = r_for(dp2);
     const int64_t tile = (int64_t)block * R;
@@ -851,35 +1003,48 @@ int run_fast(const uint8_t *blocks, int64_t N, int d, const double *cb, int K, i
     if (grid < 1) grid = 1;
 
     AssignArgs a;
-    a.blocks = blocks; a.N = N; a.d = d; a.cb = cb; a.K = K; a.kbits = kbits;
-    a.hdr = hdr; a.c16 = c16; a.bias = bias; a.cbT = cbT;
-    a.labels = labels; a.min_dist = min_dist; a.sums = sums; a.counts = counts; a.partials = partials;
+    a.blocks = blocks; a.N = N; a.d = d; a.cb = cb; a.K = K; a.kbits = kbits; a.hdr = hdr;
+    a.labels = labels; a.min_dist = min_dist; a.sums = sums; a.counts = counts;
     a.acc_mode = acc_mode; a.ntiles = ntiles;
     a.vec4 = ((d & 3) == 0) && ((reinterpret_cast<uintptr_t>(blocks) & 3) == 0);
 
     switch (dp2) {
-        case 2:  rc = launch_assign_fast_k<2>(a, packed, block, grid, lds, st); break;
-        case 4:  rc = launch_assign_fast_k<4>(a, packed, block, grid, lds, st); break;
-        case 6:  rc = launch_assign_fast_k<6>(a, packed, block, grid, lds, st); break;
-        case 8:  rc = launch_assign_fast_k<8>(a, packed, block, grid, lds, st); break;
-        case 12: rc = launch_assign_fast_k<12>(a, packed, block, grid, lds, st); break;
-        case 16: rc = launch_assign_fast_k<16>(a, packed, block, grid, lds, st); break;
-        case 24: rc = launch_assign_fast_k<24>(a, packed, block, grid, lds, st); break;
-        case 32: rc = launch_assign_fast_k<32>(a, packed, block, grid, lds, st); break;
-        case 48: rc = launch_assign_fast_k<48>(a, packed, block, grid, lds, st); break;
-        case 64: rc = launch_assign_fast_k<64>(a, packed, block, grid, lds, st); break;
-        case 96: rc = launch_assign_fast_k<96>(a, packed, block, grid, lds, st); break;
+        case 2:  rc = launch_assign_fast_k<2>(a, c16, bias, packed, block, grid, lds, st); break;
+        case 4:  rc = launch_assign_fast_k<4>(a, c16, bias, packed, block, grid, lds, st); break;
+        case 6:  rc = launch_assign_fast_k<6>(a, c16, bias, packed, block, grid, lds, st); break;
+        case 8:  rc = launch_assign_fast_k<8>(a, c16, bias, packed, block, grid, lds, st); break;
+        case 12: rc = launch_assign_fast_k<12>(a, c16, bias, packed, block, grid, lds, st); break;
+        case 16: rc = launch_assign_fast_k<16>(a, c16, bias, packed, block, grid, lds, st); break;
+        case 24: rc = launch_assign_fast_k<24>(a, c16, bias, packed, block, grid, lds, st); break;
+        case 32: rc = launch_assign_fast_k<32>(a, c16, bias, packed, block, grid, lds, st); break;
+        case 48: rc = launch_assign_fast_k<48>(a, c16, bias, packed, block, grid, lds, st); break;
+        case 64: rc = launch_assign_fast_k<64>(a, c16, bias, packed, block, grid, lds, st); break;
+        case 96: rc = launch_assign_fast_k<96>(a, c16, bias, packed, block, grid, lds, st); break;
         default: return fail(VQ_E_UNSUPPORTED, "no fast kernel for d=%d", d);
     }
     if (rc) return rc;
-    if (accumulate) {
-        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, st, partials, grid, dist_sum);
-        LAUNCH_CHECK("k_sum_partials");
-    }
+    // fix-up: 64 labels per wave trip
+    int fgrid = grid_for((N + WAVE - 1) / WAVE, 4, di.cus * 8);
+    hipLaunchKernelGGL(k_fixup, dim3(fgrid), dim3(256), 0, st, blocks, N, d, cbT, K, labels, min_dist, sums, counts);
+    LAUNCH_CHECK("k_fixup");
     return VQ_OK;
 }
 
-bool fast_supported(int d) { return d <= MAX_D_FAST && dp2_bucket(d) > 0; }
+// numpy-order sum of v[0..N) into out[0]; chunk_sums holds ceil(N / 8192) (+1) doubles of scratch.
+int run_numpy_sum(const double *v, int64_t N, double *chunk_sums, double *out, hipStream_t st) {
+    const int64_t nfull = N / NP_CHUNK;
+    if (nfull > 0) {
+        DeviceInfo di;
+        int rc = device_info(di);
+        if (rc) return rc;
+        int grid = grid_for(nfull, 4, di.cus * 8);
+        hipLaunchKernelGGL(k_npsum_chunks, dim3(grid), dim3(256), 0, st, v, nfull, chunk_sums);
+        LAUNCH_CHECK("k_npsum_chunks");
+    }
+    hipLaunchKernelGGL(k_npsum_final, dim3(1), dim3(1024), 0, st, v, N, nfull, chunk_sums, out);
+    LAUNCH_CHECK("k_npsum_final");
+    return VQ_OK;
+}
 
 }  // namespace
 
@@ -892,9 +1057,9 @@ int vq_abi_version(void) { return ABI_VERSION; }
 
 const char *vq_last_error(void) { return g_err; }
 
-size_t vq_workspace_bytes(int K, int d) {
-    if (K <= 0 || d <= 0) return 0;
-    return ws_layout(K, d).total;
+size_t vq_workspace_bytes(int K, int d, int64_t N) {
+    if (K <= 0 || d <= 0 || N < 0) return 0;
+    return ws_layout(K, d, N).total;
 }
 
 int vq_blocks_u8(const uint8_t *img, int H, int W, int C, int bh, int bw, int pad_mode, uint8_t *blocks,
@@ -939,18 +1104,42 @@ int vq_encode_l1(const uint8_t *blocks, int64_t N, int d, const double *cb, int 
     if (rc) return rc;
     if (mode != VQ_MODE_EXACT && mode != VQ_MODE_FAST) return fail(VQ_E_INVALID, "unknown mode %d", mode);
     if (N == 0) return VQ_OK;
-    if (!labels && !min_dist) return fail(VQ_E_INVALID, "both labels and min_dist are null");
+    if (!labels) return fail(VQ_E_INVALID, "null labels pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (mode == VQ_MODE_FAST && fast_supported(d)) {
-        if (!ws || ws_bytes < vq_workspace_bytes(K, d))
-            return fail(VQ_E_WORKSPACE, "workspace of %zu bytes needed, %zu given", vq_workspace_bytes(K, d), ws_bytes);
-        return run_fast(blocks, N, d, cb, K, labels, min_dist, nullptr, nullptr, nullptr, false, ws, st);
+        rc = check_ws(ws, ws_bytes, K, d, 0);
+        if (rc) return rc;
+        rc = run_prepare(cb, K, d, ws, st);
+        if (rc) return rc;
+        return run_fast(blocks, N, d, cb, K, labels, min_dist, nullptr, nullptr, ws, st);
     }
     int grid = grid_for(N, 256, 16384);
     hipLaunchKernelGGL(k_assign_exact, dim3(grid), dim3(256), 0, st, blocks, N, d, cb, K, labels, min_dist,
-                       (unsigned long long *)nullptr, (unsigned long long *)nullptr, (double *)nullptr);
+                       (unsigned long long *)nullptr, (unsigned long long *)nullptr);
     LAUNCH_CHECK("k_assign_exact");
     return VQ_OK;
+}
+
+int vq_codebook_prepare(const double *cb, int K, int d, void *ws, size_t ws_bytes, void *stream) {
+    if (!cb) return fail(VQ_E_INVALID, "null codebook pointer");
+    if (K <= 0 || d <= 0) return fail(VQ_E_INVALID, "need K > 0 and d > 0");
+    if (K > MAX_K) return fail(VQ_E_UNSUPPORTED, "K=%d exceeds %d", K, MAX_K);
+    if (!fast_supported(d)) return fail(VQ_E_UNSUPPORTED, "d=%d is beyond the prepared (fast) kernels", d);
+    int rc = check_ws(ws, ws_bytes, K, d, 0);
+    if (rc) return rc;
+    return run_prepare(cb, K, d, ws, static_cast<hipStream_t>(stream));
+}
+
+int vq_encode_l1_prepared(const uint8_t *blocks, int64_t N, int d, const double *cb, int K, int32_t *labels,
+                          double *min_dist, void *ws, size_t ws_bytes, void *stream) {
+    int rc = check_common(blocks, N, d, cb, K);
+    if (rc) return rc;
+    if (!fast_supported(d)) return fail(VQ_E_UNSUPPORTED, "d=%d is beyond the prepared (fast) kernels", d);
+    rc = check_ws(ws, ws_bytes, K, d, 0);
+    if (rc) return rc;
+    if (N == 0) return VQ_OK;
+    if (!labels) return fail(VQ_E_INVALID, "null labels pointer");
+    return run_fast(blocks, N, d, cb, K, labels, min_dist, nullptr, nullptr, ws, static_cast<hipStream_t>(stream));
 }
 
 int vq_accum_labels(const uint8_t *blocks, int64_t N, int d, const int32_t *labels, int K, uint64_t *sums,
@@ -966,32 +1155,40 @@ int vq_accum_labels(const uint8_t *blocks, int64_t N, int d, const int32_t *labe
     return VQ_OK;
 }
 
+int vq_numpy_sum_f64(const double *v, int64_t N, double *out, double *chunk_sums, void *stream) {
+    if (N < 0) return fail(VQ_E_INVALID, "need N >= 0");
+    if (!out || !chunk_sums || (!v && N != 0)) return fail(VQ_E_INVALID, "null pointer");
+    return run_numpy_sum(v, N, chunk_sums, out, static_cast<hipStream_t>(stream));
+}
+
 int vq_lbg_accum(const uint8_t *blocks, int64_t N, int d, const double *cb, int K, uint64_t *sums, uint64_t *counts,
-                 double *dist_sum, int32_t *labels, int mode, void *ws, size_t ws_bytes, void *stream) {
+                 int32_t *labels, double *min_dist, double *dist_sum, double *chunk_sums, int mode, void *ws,
+                 size_t ws_bytes, void *stream) {
     int rc = check_common(blocks, N, d, cb, K);
     if (rc) return rc;
     if (!sums || !counts || !dist_sum) return fail(VQ_E_INVALID, "null sums, counts or dist_sum pointer");
+    if (N != 0 && (!labels || !min_dist)) return fail(VQ_E_INVALID, "null labels or min_dist pointer");
     if (mode != VQ_MODE_EXACT && mode != VQ_MODE_FAST) return fail(VQ_E_INVALID, "unknown mode %d", mode);
-    if (!ws || ws_bytes < vq_workspace_bytes(K, d))
-        return fail(VQ_E_WORKSPACE, "workspace of %zu bytes needed, %zu given", vq_workspace_bytes(K, d), ws_bytes);
+    rc = check_ws(ws, ws_bytes, K, d, N);
+    if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (N == 0) {
-        HIP_TRY(hipMemsetAsync(dist_sum, 0, sizeof(double), st));
-        return VQ_OK;
+    unsigned long long *s64 = reinterpret_cast<unsigned long long *>(sums);
+    unsigned long long *c64 = reinterpret_cast<unsigned long long *>(counts);
+    if (N > 0) {
+        if (mode == VQ_MODE_FAST && fast_supported(d)) {
+            rc = run_prepare(cb, K, d, ws, st);
+            if (rc) return rc;
+            rc = run_fast(blocks, N, d, cb, K, labels, min_dist, s64, c64, ws, st);
+            if (rc) return rc;
+        } else {
+            int grid = grid_for(N, 256, 16384);
+            hipLaunchKernelGGL(k_assign_exact, dim3(grid), dim3(256), 0, st, blocks, N, d, cb, K, labels, min_dist, s64, c64);
+            LAUNCH_CHECK("k_assign_exact");
+        }
     }
-    if (mode == VQ_MODE_FAST && fast_supported(d))
-        return run_fast(blocks, N, d, cb, K, labels, nullptr, reinterpret_cast<unsigned long long *>(sums),
-                        reinterpret_cast<unsigned long long *>(counts), dist_sum, true, ws, st);
-    // EXACT mode (also serves dimensions beyond the SAD filter kernels)
-    double *partials = reinterpret_cast<double *>(static_cast<char *>(ws) + ws_layout(K, d).partials);
-    int grid = grid_for(N, 256, MAX_GRID);
-    hipLaunchKernelGGL(k_assign_exact, dim3(grid), dim3(256), 0, st, blocks, N, d, cb, K, labels, (double *)nullptr,
-                       reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts),
-                       partials);
-    LAUNCH_CHECK("k_assign_exact");
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, st, partials, grid, dist_sum);
-    LAUNCH_CHECK("k_sum_partials");
-    return VQ_OK;
+    double *cs = chunk_sums ? chunk_sums
+                            : reinterpret_cast<double *>(static_cast<char *>(ws) + ws_layout(K, d, N).chunks);
+    return run_numpy_sum(min_dist, N, cs, dist_sum, st);
 }
 
 int vq_lbg_finalize(const uint64_t *sums, const uint64_t *counts, const double *cb_old, int K, int d, double *cb_new,
@@ -1024,11 +1221,11 @@ int vq_decode_u8(const int32_t *labels, int nr, int nc, const double *cb, int K,
     int64_t d64 = (int64_t)bh * bw * C;
     if (d64 > (1 << 24)) return fail(VQ_E_UNSUPPORTED, "block too large");
     int d = (int)d64;
-    if (!ws || ws_bytes < vq_workspace_bytes(K, d))
-        return fail(VQ_E_WORKSPACE, "workspace of %zu bytes needed, %zu given", vq_workspace_bytes(K, d), ws_bytes);
+    int rc = check_ws(ws, ws_bytes, K, d, 0);
+    if (rc) return rc;
     if (nr == 0 || nc == 0) return VQ_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    WsLayout L = ws_layout(K, d);
+    WsLayout L = ws_layout(K, d, 0);
     uint8_t *cb8 = reinterpret_cast<uint8_t *>(static_cast<char *>(ws) + L.cb_u8);
     int64_t n = (int64_t)K * d;
     hipLaunchKernelGGL(k_cb_to_u8, dim3(grid_for(n, 256, 4096)), dim3(256), 0, st, cb, n, cb8);

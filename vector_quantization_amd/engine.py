@@ -34,13 +34,16 @@ class HipEngine:
             raise ValueError("mode must be 'fast' or 'exact'")
         self.mode = VQ_MODE_FAST if mode == "fast" else VQ_MODE_EXACT
         self._ws = None
+        self._scratch_n = -1
+        self._labels_scratch = None
+        self._dist_scratch = None
 
     # -- plumbing ----------------------------------------------------------------------------
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def _workspace(self, K, d):
-        need = lib.vq_workspace_bytes(int(K), int(d))
+    def _workspace(self, K, d, N=0):
+        need = lib.vq_workspace_bytes(int(K), int(d), int(N))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=self.device)
         return self._ws
@@ -90,23 +93,69 @@ class HipEngine:
                   "vq_encode_l1")
         return (labels, mind) if want_dist else labels
 
+    def prepare_codebook(self, cb, d=None):
+        """Fill a private workspace for cb; returns a handle for encode_prepared (many batches, one
+        codebook)."""
+        cb = self._dev(cb, torch.float64)
+        K, d = cb.shape
+        need = lib.vq_workspace_bytes(int(K), int(d), 0)
+        ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib.vq_codebook_prepare(_ptr(cb), K, d, _ptr(ws), ws.numel(), self._stream()),
+                  "vq_codebook_prepare")
+        return (cb, ws)
+
+    def encode_prepared(self, blocks, prepared, labels=None, want_dist=False):
+        cb, ws = prepared
+        N, d = blocks.shape
+        K = cb.shape[0]
+        if labels is None:
+            labels = torch.empty(N, dtype=torch.int32, device=self.device)
+        mind = torch.empty(N, dtype=torch.float64, device=self.device) if want_dist else None
+        with torch.cuda.device(self.device):
+            check(lib.vq_encode_l1_prepared(_ptr(blocks), N, d, _ptr(cb), K, _ptr(labels), _ptr(mind), _ptr(ws),
+                                            ws.numel(), self._stream()), "vq_encode_l1_prepared")
+        return (labels, mind) if want_dist else labels
+
     # -- fused LBG assignment + accumulation (VQ_Full.py:77-90) -------------------------------------
-    def lbg_accum(self, blocks, cb, want_labels=False, mode=None):
-        """Returns (acc, dist_sum[, labels]); acc is one int64 buffer [K*d sums | K counts] so that a
-        multi-GPU job can all-reduce it in one collective."""
+    def lbg_accum(self, blocks, cb, want_labels=False, mode=None, want_chunks=False):
+        """Returns (acc, dist_sum[, labels][, chunk_sums]); acc is one int64 buffer
+        [K*d sums | K counts] so that a multi-GPU job can all-reduce it in one collective.  dist_sum
+        is the sum of the winning distances in numpy's summation order."""
         N, d = blocks.shape
         cb = self._dev(cb, torch.float64)
         K = cb.shape[0]
         acc = torch.zeros(K * d + K, dtype=torch.int64, device=self.device)
         dist = torch.empty(1, dtype=torch.float64, device=self.device)
-        labels = torch.empty(N, dtype=torch.int32, device=self.device) if want_labels else None
-        ws = self._workspace(K, d)
+        if self._scratch_n < N:
+            self._labels_scratch = torch.empty(N, dtype=torch.int32, device=self.device)
+            self._dist_scratch = torch.empty(N, dtype=torch.float64, device=self.device)
+            self._scratch_n = N
+        labels = torch.empty(N, dtype=torch.int32, device=self.device) if want_labels else self._labels_scratch
+        chunks = torch.empty(-(-N // 8192) + 1, dtype=torch.float64, device=self.device) if want_chunks else None
+        ws = self._workspace(K, d, N)
         sums, counts = acc[: K * d], acc[K * d:]
         with torch.cuda.device(self.device):
-            check(lib.vq_lbg_accum(_ptr(blocks), N, d, _ptr(cb), K, _ptr(sums), _ptr(counts), _ptr(dist),
-                                   _ptr(labels), self.mode if mode is None else mode, _ptr(ws), ws.numel(),
-                                   self._stream()), "vq_lbg_accum")
-        return (acc, dist, labels) if want_labels else (acc, dist)
+            check(lib.vq_lbg_accum(_ptr(blocks), N, d, _ptr(cb), K, _ptr(sums), _ptr(counts), _ptr(labels),
+                                   _ptr(self._dist_scratch), _ptr(dist), _ptr(chunks),
+                                   self.mode if mode is None else mode, _ptr(ws), ws.numel(), self._stream()),
+                  "vq_lbg_accum")
+        out = [acc, dist]
+        if want_labels:
+            out.append(labels)
+        if want_chunks:
+            out.append(chunks[: -(-N // 8192)])
+        return tuple(out)
+
+    def numpy_sum(self, v):
+        """Sum of a float64 vector in numpy's summation order (np.add.reduce), on the device."""
+        v = self._dev(v, torch.float64).reshape(-1)
+        N = v.numel()
+        out = torch.empty(1, dtype=torch.float64, device=self.device)
+        chunks = torch.empty(-(-N // 8192) + 1, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib.vq_numpy_sum_f64(_ptr(v), N, _ptr(out), _ptr(chunks), self._stream()), "vq_numpy_sum_f64")
+        return out
 
     def accum_labels(self, blocks, labels, K):
         N, d = blocks.shape

@@ -3,8 +3,9 @@
 The engine does the per-vector work on its GPU; this module owns the split schedule, the
 stop rule and -- when the block vectors are sharded over several GPUs -- the per-iteration
 exchange: one all-reduce of the integer [sums | counts] buffer and one all-gather of the fp64
-distance partials, which are then added in rank order so that every rank computes the same
-distortion bit for bit.  Integer sums make the n-GPU codebook identical to the 1-GPU one.
+per-chunk distance sums, which every rank then adds in rank order.  Integer sums make the n-GPU
+codebook identical to the 1-GPU one; with 8192-aligned shards the distortion (numpy's summation
+order) is identical too, so the stop rule fires at the same iteration.
 """
 import math
 
@@ -30,15 +31,43 @@ def _allreduce_sum_(t, group):
     return t
 
 
-def _ordered_sum(value, group):
-    """Sum of one fp64 scalar per rank, added in rank order on every rank."""
+NP_CHUNK = 8192   # elements per pairwise-summed chunk of numpy's reduction (and of vq_numpy_sum_f64)
+
+
+def shards_chunk_aligned(n_local, group):
+    """True when the ranks' shards, concatenated in rank order, keep numpy's 8192-element chunk
+    boundaries inside shards: every rank but the last one holding data has a multiple of 8192."""
     import torch.distributed as dist
     world = dist.get_world_size(group=group)
-    gathered = [torch.empty_like(value) for _ in range(world)]
-    dist.all_gather(gathered, value, group=group)
+    sizes = [None] * world
+    dist.all_gather_object(sizes, int(n_local), group=group)
+    holders = [r for r in range(world) if sizes[r] > 0]
+    return all(sizes[r] % NP_CHUNK == 0 for r in holders[:-1]), sizes
+
+
+def _global_distance_sum(dist_sum, chunks, sizes, aligned, group):
+    """Sum of all ranks' winning distances.  With chunk-aligned shards it is the left-to-right total
+    of every rank's per-chunk sums in rank order -- bit for bit what one process computes on the
+    concatenated data; otherwise the per-rank sums added in rank order."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group=group)
+    if aligned:
+        width = max(-(-n // NP_CHUNK) for n in sizes)
+        mine = torch.zeros(max(width, 1), dtype=torch.float64, device=chunks.device)
+        mine[: chunks.numel()] = chunks
+    else:
+        mine = dist_sum.reshape(1)
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine, group=group)
+    host = torch.stack(gathered).cpu().numpy()
+    if aligned:
+        import numpy as np
+        parts = [host[r, : -(-sizes[r] // NP_CHUNK)] for r in range(world)]
+        seq = np.concatenate(parts) if parts else np.zeros(0)
+        return float(np.cumsum(seq)[-1]) if seq.size else 0.0      # cumsum adds strictly left to right
     total = 0.0
-    for g in torch.stack(gathered).reshape(-1).cpu().tolist():
-        total += g
+    for r in range(world):
+        total += float(host[r, 0])
     return total
 
 
@@ -58,14 +87,18 @@ def initial_centroid(engine, blocks, group=None):
     return centroid, n_total
 
 
-def lbg_iteration(engine, blocks, cb, n_total, group=None):
+def lbg_iteration(engine, blocks, cb, n_total, group=None, shard_info=None):
     """One pass of VQ_Full.py:77-90.  Returns (new codebook, distortion as a Python float)."""
-    acc, dist = engine.lbg_accum(blocks, cb)
-    if group is not None:
-        _allreduce_sum_(acc, group)
-        total = _ordered_sum(dist, group)
-    else:
+    if group is None:
+        acc, dist = engine.lbg_accum(blocks, cb)
         total = float(dist.item())
+    else:
+        if shard_info is None:
+            shard_info = shards_chunk_aligned(blocks.shape[0], group)
+        aligned, sizes = shard_info
+        acc, dist, chunks = engine.lbg_accum(blocks, cb, want_chunks=True)
+        _allreduce_sum_(acc, group)
+        total = _global_distance_sum(dist, chunks, sizes, aligned, group)
     new_cb = engine.lbg_finalize(acc, cb)
     return new_cb, total / float(n_total)
 
@@ -85,6 +118,7 @@ def train_lbg(engine, blocks, k, epsilon=0.01, threshold=0.001, max_iterations=1
             f"Invalid quantization level k={k}: cannot exceed the total number of image blocks ({n_total})."
         )
     cb = centroid
+    shard_info = shards_chunk_aligned(blocks.shape[0], group) if group is not None else None
     iters, conv, distortions = [], [], []
     stage = 0
     while cb.shape[0] < k:
@@ -94,7 +128,7 @@ def train_lbg(engine, blocks, k, epsilon=0.01, threshold=0.001, max_iterations=1
         forced = None if iters_per_stage is None else int(iters_per_stage[stage])
         limit = max_iterations if forced is None else forced
         for i in range(limit):
-            cb, distortion = lbg_iteration(engine, blocks, cb, n_total, group)
+            cb, distortion = lbg_iteration(engine, blocks, cb, n_total, group, shard_info)
             distortions.append(distortion)
             done += 1
             if forced is None and prev != float("inf"):
