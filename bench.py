@@ -98,7 +98,7 @@ def main():
     N, d = blocks.shape
     crop = eng.blocks_from_image(structured_image(2048, 2048, seed=0, device=device), BH, BW)
     cb = train_lbg(eng, crop, K_CODEBOOK, log=None).codebook          # same codebook on every rank (seed 0)
-    prepared = eng.prepare_codebook(cb)
+    prepared = eng.prepare_codebook(cb, blocks.shape[0])
     labels = torch.empty(N, dtype=torch.int32, device=device)
     nr, nc = H // BH, W // BW
 

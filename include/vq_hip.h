@@ -46,9 +46,9 @@ int vq_abi_version(void);
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char *vq_last_error(void);
 
-/* Bytes of device scratch for a (K, d) codebook.  N is the number of block vectors of the
- * vq_lbg_accum call the workspace is for (it sizes the per-chunk distance sums); pass N = 0 for
- * vq_encode_l1, vq_codebook_prepare / vq_encode_l1_prepared and vq_decode_u8.  Pure host arithmetic. */
+/* Bytes of device scratch for a (K, d) codebook and calls on up to N block vectors (N sizes the
+ * queue of vectors that need the fp64 re-check and the per-chunk distance sums; at most 2^32 - 16
+ * vectors per call).  vq_codebook_prepare and vq_decode_u8 only need N = 0.  Pure host arithmetic. */
 size_t vq_workspace_bytes(int K, int d, int64_t N);
 
 /* Block extraction.  Replaces Codebook.__init__'s padding (VQ_Full.py:23-33) and

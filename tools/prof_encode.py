@@ -17,7 +17,7 @@ img = structured_image(8192, 8192, 1000, dev)
 blocks = eng.blocks_from_image(img, 4, 4)
 crop = eng.blocks_from_image(structured_image(2048, 2048, 0, dev), 4, 4)
 cb = train_lbg(eng, crop, 256, log=None).codebook
-prepared = eng.prepare_codebook(cb)
+prepared = eng.prepare_codebook(cb, blocks.shape[0])
 labels = torch.empty(blocks.shape[0], dtype=torch.int32, device=dev)
 torch.cuda.synchronize()
 for _ in range(reps):

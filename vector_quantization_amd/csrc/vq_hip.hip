@@ -68,6 +68,18 @@ constexpr int64_t NP_CHUNK = 8192;      // numpy's reduction buffer: elements pe
 constexpr int MAX_D_FAST = 192;         // largest vector dimension of the SAD filter kernels
 constexpr int MAX_K = 1 << 20;
 
+// Tuning knobs of the d <= 16 filter kernels: vectors per lane, codewords per scalar-load batch,
+// resident 256-thread workgroups per CU the grid is sized for.
+#ifndef VQ_R8
+#define VQ_R8 4
+#endif
+#ifndef VQ_U8
+#define VQ_U8 4
+#endif
+#ifndef VQ_WG_PER_CU
+#define VQ_WG_PER_CU 8
+#endif
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Workspace layout (all offsets multiples of 256 bytes).
@@ -78,6 +90,8 @@ struct WsLayout {
     size_t cbT;        // d * K doubles: transposed fp64 codebook
     size_t cb_u8;      // K * d bytes: codebook truncated to uint8 (decode)
     size_t chunks;     // ceil(N / 8192) + 1 doubles: per-chunk sums of the distance array
+    size_t qcount;     // one 256-byte slot: number of queued (ambiguous) vectors
+    size_t queue;      // N uint32: indices of the vectors the fix-up kernel must re-check
     size_t total;
 };
 
@@ -94,6 +108,8 @@ WsLayout ws_layout(int K, int d, int64_t N) {
     L.cbT = off;      off += align_up((size_t)K * d * 8, 256);
     L.cb_u8 = off;    off += align_up((size_t)K * d, 256);
     L.chunks = off;   off += align_up((size_t)((N + NP_CHUNK - 1) / NP_CHUNK + 1) * 8, 256);
+    L.qcount = off;   off += 256;
+    L.queue = off;    off += align_up((size_t)N * 4, 256);
     L.total = off;
     return L;
 }
@@ -136,30 +152,57 @@ __device__ __forceinline__ void wave_argmin(double &best, int &bidx) {
     }
 }
 
-// Whole-wave exact search for ONE vector (xrow: d bytes, wave-uniform address).  Lane l evaluates
-// codewords l, l+64, ... in sequential fp64 against the transposed codebook cbT[e*K + k].
-__device__ __forceinline__ void exact_search_wave(const uint8_t *__restrict__ xrow, int d,
-                                                  const double *__restrict__ cbT, int K, int lane,
-                                                  int &out_idx, double &out_dist) {
+// Whole-wave exact search for ONE vector (xrow: d bytes, wave-uniform address; xv0: lane e's copy
+// of x[e] for e < 64, already loaded).  Lane l evaluates codewords l, l+64, ... in sequential fp64
+// against the transposed codebook cbT[e*K + k] (in LDS when LDS_CB).  Loads are issued eight
+// elements (x four codewords) at a time so that one memory round trip serves 32 terms; the
+// additions still run in element order, one chain per codeword.
+template <bool LDS_CB>
+__device__ __forceinline__ void exact_search_wave(uint32_t xv0, const uint8_t *__restrict__ xrow, int d,
+                                                  const double *__restrict__ cbT, const double *s_cbT, int K,
+                                                  int lane, int &out_idx, double &out_dist) {
     double best = __builtin_huge_val();
     int bidx = 0x7fffffff;
     for (int k0 = 0; k0 < K; k0 += 4 * WAVE) {
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int e = 0; e < d; ++e) {
-            double xv = (double)xrow[e];
-            const double *col = cbT + (size_t)e * K + k0 + lane;
+        int kk[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int k = k0 + j * WAVE + lane;
-                double c = (k < K) ? col[j * WAVE] : 0.0;
-                acc[j] += fabs(xv - c);
+        for (int q = 0; q < 4; ++q) {
+            int k = k0 + q * WAVE + lane;
+            kk[q] = k < K ? k : K - 1;                         // clamped: loads stay in bounds
+        }
+        for (int ebase = 0; ebase < d; ebase += WAVE) {
+            const int ecount = d - ebase < WAVE ? d - ebase : WAVE;
+            uint32_t xv = xv0;                                  // lane e holds x[ebase + e]
+            if (ebase > 0) xv = lane < ecount ? (uint32_t)xrow[ebase + lane] : 0u;
+            int e0 = 0;
+            for (; e0 + 8 <= ecount; e0 += 8) {                  // full batches: no predication
+                double c[8][4];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const size_t off = (size_t)(ebase + e0 + j) * K;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) c[j][q] = LDS_CB ? s_cbT[off + kk[q]] : cbT[off + kk[q]];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const double xe = (double)__builtin_amdgcn_readlane(xv, e0 + j);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] += fabs(xe - c[j][q]);
+                }
+            }
+            for (; e0 < ecount; ++e0) {                          // tail of a dimension that is not a multiple of 8
+                const size_t off = (size_t)(ebase + e0) * K;
+                const double xe = (double)__builtin_amdgcn_readlane(xv, e0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] += fabs(xe - (LDS_CB ? s_cbT[off + kk[q]] : cbT[off + kk[q]]));
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int k = k0 + j * WAVE + lane;
-            if (k < K && acc[j] < best) {
-                best = acc[j];
+        for (int q = 0; q < 4; ++q) {
+            int k = k0 + q * WAVE + lane;
+            if (k < K && acc[q] < best) {
+                best = acc[q];
                 bidx = k;
             }
         }
@@ -258,7 +301,7 @@ __global__ __launch_bounds__(256) void k_finalize(const unsigned long long *__re
 // ------------------------------------------------------------------------------------------------
 // codebook preparation for the SAD filter (one workgroup)
 // ------------------------------------------------------------------------------------------------
-constexpr int PREP_HASH_CAP = 8192;     // codebooks up to this size get the duplicate-row scan
+constexpr int PREP_HASH_CAP = 4096;     // codebooks up to this size get the duplicate-row detection
 
 __device__ __forceinline__ unsigned long long mix64(unsigned long long h, unsigned long long v) {
     h ^= v;
@@ -267,15 +310,25 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long h, unsign
     return h;
 }
 
+// Dynamic LDS: an open-addressing table of 2*K slots (keys = 64-bit row hashes), the K row hashes,
+// then per slot the smallest row index seen for its key.
 __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb, int K, int d, int dp2,
                                                   PrepHeader *__restrict__ hdr, uint32_t *__restrict__ c16,
                                                   uint32_t *__restrict__ bias, double *__restrict__ cbT) {
-    extern __shared__ __align__(16) unsigned long long s_hash[];   // min(K, PREP_HASH_CAP) row hashes
+    extern __shared__ __align__(16) unsigned long long s_keys[];
     __shared__ uint32_t s_cmax;
     __shared__ uint32_t s_emax;
+    const bool scan_dups = K <= PREP_HASH_CAP && K > 1;
+    const uint32_t T = scan_dups ? 2u * (uint32_t)K : 0u;       // table slots
+    unsigned long long *s_rowhash = s_keys + T;                  // K entries
+    uint32_t *s_first = reinterpret_cast<uint32_t *>(s_rowhash + (scan_dups ? K : 0));
     if (threadIdx.x == 0) {
         s_cmax = 0;
         s_emax = 0;
+    }
+    for (uint32_t i = threadIdx.x; i < T; i += blockDim.x) {
+        s_keys[i] = 0ull;
+        s_first[i] = 0xffffffffu;
     }
     __syncthreads();
     // phase A: largest entry (ceil, saturated; non-finite counts as huge)
@@ -295,56 +348,89 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
     int s = 8;
     while (s > 0 && ((uint64_t)cmax << s) > 65535ull) --s;
     const double scale = (double)(1u << s);
-    const bool scan_dups = K <= PREP_HASH_CAP;
-    // phase B: one thread per codeword: fixed-point row, rounding-error bound, transposed copy, row hash
+    // phase B: one thread per codeword: fixed-point row, rounding-error bound, transposed copy, row
+    // hash.  The row is read eight entries at a time (loads first, arithmetic after).
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
         const double *row = cb + (size_t)k * d;
         double err = 0.0;
         unsigned long long h = 0x243F6A8885A308D3ull;
-        for (int p = 0; p < dp2; ++p) {
-            uint32_t pair = 0;
+        for (int p0 = 0; p0 < dp2; p0 += 4) {
+            double c[8];
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                int e = 2 * p + hh;
-                if (e < d) {
-                    double c = row[e];
-                    double t = c * scale;
-                    double q = rint(t);
-                    if (!(q >= 0.0)) q = 0.0;          // also catches NaN
-                    if (q > 65535.0) q = 65535.0;
-                    double de = fabs(t - q);
-                    if (!(de == de)) de = 4.0e9;
-                    err += de;
-                    pair |= ((uint32_t)q) << (16 * hh);
-                    cbT[(size_t)e * K + k] = c;
-                    h = mix64(h, (unsigned long long)__double_as_longlong(c));
+            for (int j = 0; j < 8; ++j) {
+                const int e = 2 * p0 + j;
+                c[j] = row[e < d ? e : d - 1];
+            }
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                const int p = p0 + pp;
+                if (p < dp2) {
+                    uint32_t pair = 0;
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int e = 2 * p + hh;
+                        if (e < d) {
+                            const double cv = c[2 * pp + hh];
+                            double t = cv * scale;
+                            double q = rint(t);
+                            if (!(q >= 0.0)) q = 0.0;          // also catches NaN
+                            if (q > 65535.0) q = 65535.0;
+                            double de = fabs(t - q);
+                            if (!(de == de)) de = 4.0e9;
+                            err += de;
+                            pair |= ((uint32_t)q) << (16 * hh);
+                            cbT[(size_t)e * K + k] = cv;
+                            h = mix64(h, (unsigned long long)__double_as_longlong(cv));
+                        }
+                    }
+                    c16[(size_t)k * dp2 + p] = pair;
                 }
             }
-            c16[(size_t)k * dp2 + p] = pair;
         }
         // strict integer upper bound of err (plus slack for the fp64 rounding of err itself)
         uint32_t ek = (err < 2.0e9) ? (uint32_t)err + 2u : 0x7fffffffu;
         atomicMax(&s_emax, ek);
-        if (scan_dups) s_hash[k] = h;
+        // record the smallest index of each distinct row hash (0 marks an empty slot)
+        if (scan_dups) {
+            if (h == 0ull) h = 1ull;
+            s_rowhash[k] = h;
+            uint32_t slot = (uint32_t)(h % T);
+            for (uint32_t probe = 0; probe < T; ++probe) {
+                unsigned long long old = atomicCAS(&s_keys[slot], 0ull, h);
+                if (old == 0ull || old == h) {
+                    atomicMin(&s_first[slot], (uint32_t)k);
+                    break;
+                }
+                slot = slot + 1 == T ? 0 : slot + 1;
+            }
+        }
     }
     __syncthreads();
-    // phase C: is row k bit-identical to an earlier row?  Hashes are compared in LDS; the rows
-    // themselves only on a hash match.  Identical rows give identical distances, so the later one
-    // can never win and gets the never-competes bit.
+    // phase C: row k is a duplicate when the first row with its hash is an earlier, bit-identical
+    // row.  Identical rows give identical distances, so the later one can never win (ties go to the
+    // lower index) and gets the never-competes bit.  A missed duplicate only costs re-checks.
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
         uint32_t dup = 0;
         if (scan_dups) {
-            const unsigned long long hk = s_hash[k];
-            const unsigned long long *rowb = reinterpret_cast<const unsigned long long *>(cb + (size_t)k * d);
-            for (int j = 0; j < k; ++j) {
-                if (s_hash[j] != hk) continue;
-                const unsigned long long *rj = reinterpret_cast<const unsigned long long *>(cb + (size_t)j * d);
-                int e = 0;
-                while (e < d && rj[e] == rowb[e]) ++e;
-                if (e == d) {
-                    dup = 1;
+            const double *row = cb + (size_t)k * d;
+            const unsigned long long h = s_rowhash[k];
+            uint32_t slot = (uint32_t)(h % T);
+            uint32_t first = 0xffffffffu;
+            for (uint32_t probe = 0; probe < T; ++probe) {
+                unsigned long long key = s_keys[slot];
+                if (key == h) {
+                    first = s_first[slot];
                     break;
                 }
+                if (key == 0ull) break;
+                slot = slot + 1 == T ? 0 : slot + 1;
+            }
+            if (first < (uint32_t)k) {
+                const unsigned long long *rowb = reinterpret_cast<const unsigned long long *>(row);
+                const unsigned long long *rj = reinterpret_cast<const unsigned long long *>(cb + (size_t)first * d);
+                int e = 0;
+                while (e < d && rj[e] == rowb[e]) ++e;
+                dup = e == d ? 1u : 0u;
             }
         }
         bias[k] = (uint32_t)k | (dup << 31);
@@ -375,8 +461,10 @@ struct AssignArgs {
     int K;
     int kbits;
     const PrepHeader *hdr;
-    int32_t *labels;            // N; a vector whose filter result is ambiguous gets -1 - (filter's index)
+    int32_t *labels;            // N; written for unambiguous vectors only
     double *min_dist;           // nullable; written for unambiguous vectors only
+    uint32_t *queue;            // indices of ambiguous vectors, appended in no particular order
+    uint32_t *qcount;           // number of queue entries (zeroed before the launch)
     unsigned long long *sums;   // ACC_*: (K, d)
     unsigned long long *counts; // ACC_*: (K)
     int acc_mode;
@@ -385,10 +473,11 @@ struct AssignArgs {
 };
 
 template <int DP2, int R, int KEYMODE>
-__global__ __launch_bounds__(512) void k_assign_fast(const AssignArgs a, const uint32_t *__restrict__ c16,
+__global__ __launch_bounds__(1024) void k_assign_fast(const AssignArgs a, const uint32_t *__restrict__ c16,
                                                      const uint32_t *__restrict__ bias) {
     extern __shared__ __align__(16) uint32_t s_tab[];   // ACC_LDS: K * (d + 1) words, [sums | count] per codeword
     const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
     const int BLOCK = blockDim.x;
     const int d = a.d, K = a.K;
     const int acc_mode = a.acc_mode;
@@ -454,7 +543,7 @@ __global__ __launch_bounds__(512) void k_assign_fast(const AssignArgs a, const u
         }
         // Codewords are fetched by scalar loads (wave-uniform addresses) in batches of U, so that
         // one scalar-memory wait is paid per U * R * (DP2 + 3) vector instructions.
-        constexpr int U = DP2 <= 8 ? 4 : (DP2 <= 16 ? 2 : 1);
+        constexpr int U = DP2 <= 8 ? VQ_U8 : (DP2 <= 16 ? 2 : 1);
         auto step = [&](const uint32_t *cw, uint32_t b, int k) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -495,7 +584,7 @@ __global__ __launch_bounds__(512) void k_assign_fast(const AssignArgs a, const u
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int64_t n = base + (int64_t)r * BLOCK + tid;
-            if (n >= a.N) continue;
+            const bool valid = n < a.N;
             uint32_t s1, s2;
             int idx;
             if (KEYMODE == KEY_PACKED) {
@@ -507,10 +596,18 @@ __global__ __launch_bounds__(512) void k_assign_fast(const AssignArgs a, const u
                 s1 = m1[r];
                 s2 = m2[r];
             }
-            if (s2 - s1 <= window) {
-                a.labels[n] = -1 - idx;                 // near-tie: the fix-up kernel decides in fp64
-                continue;
+            // near-tie: the filter cannot rank the two best candidates; queue the vector for the
+            // fp64 fix-up kernel (one atomic per wave that has any)
+            const bool amb = valid && (s2 - s1 <= window);
+            const unsigned long long amask = __ballot(amb);
+            if (amask) {
+                const int leader = __ffsll((long long)amask) - 1;
+                uint32_t qbase = 0;
+                if (lane == leader) qbase = atomicAdd(a.qcount, (uint32_t)__popcll(amask));
+                qbase = __builtin_amdgcn_readlane(qbase, leader);
+                if (amb) a.queue[qbase + (uint32_t)__popcll(amask & ((1ull << lane) - 1ull))] = (uint32_t)n;
             }
+            if (!valid || amb) continue;
             a.labels[n] = idx;
             if (want_dist) {
                 const double *crow = a.cb + (size_t)idx * d;
@@ -581,33 +678,51 @@ __global__ __launch_bounds__(512) void k_assign_fast(const AssignArgs a, const u
     }
 }
 
-// Fix-up pass of FAST mode: every vector whose label is negative is searched again by a whole
-// wave in sequential fp64 (exact_search_wave); its final label, its distance and -- when sums is
-// non-null -- its contribution to the cluster sums are written here.  One wave scans 64 labels
-// per trip; the result does not depend on how vectors are spread over waves.
-__global__ __launch_bounds__(256) void k_fixup(const uint8_t *__restrict__ blocks, int64_t N, int d,
-                                               const double *__restrict__ cbT, int K, int32_t *__restrict__ labels,
-                                               double *__restrict__ min_dist, unsigned long long *__restrict__ sums,
-                                               unsigned long long *__restrict__ counts) {
+// Fix-up pass of FAST mode: every queued vector is searched again by a whole wave in sequential
+// fp64 (exact_search_wave); its label, its distance and -- when sums is non-null -- its
+// contribution to the cluster sums are written here.  Waves stride over the queue, so the work is
+// balanced however the ambiguous vectors cluster in the image; results do not depend on queue order.
+// A wave fetches the queue entries and vector rows of four items at once (two memory round trips
+// per four items); with LDS_CB the transposed codebook is staged in LDS once per workgroup.
+template <bool LDS_CB>
+__global__ __launch_bounds__(1024) void k_fixup(const uint8_t *__restrict__ blocks, int d,
+                                                const double *__restrict__ cbT, int K,
+                                                const uint32_t *__restrict__ queue,
+                                                const uint32_t *__restrict__ qcount, int32_t *__restrict__ labels,
+                                                double *__restrict__ min_dist, unsigned long long *__restrict__ sums,
+                                                unsigned long long *__restrict__ counts) {
+    extern __shared__ __align__(16) double s_cbT[];
     const int lane = threadIdx.x & (WAVE - 1);
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int64_t ngroups = (N + WAVE - 1) / WAVE;
-    for (int64_t g = wave; g < ngroups; g += nwaves) {
-        const int64_t n = g * WAVE + lane;
-        const int lab = n < N ? labels[n] : 0;
-        unsigned long long mask = __ballot(lab < 0);
-        while (mask) {
-            const int src = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            const int64_t nsrc = g * WAVE + src;              // wave-uniform
-            const uint8_t *xrow = blocks + (size_t)nsrc * d;
+    const uint32_t waves_per_wg = blockDim.x >> 6;
+    const uint32_t wave = blockIdx.x * waves_per_wg + (threadIdx.x >> 6);
+    const uint32_t nwaves = gridDim.x * waves_per_wg;
+    const uint32_t count = qcount[0];
+    if (blockIdx.x * waves_per_wg >= count) return;            // nothing for this workgroup (uniform)
+    if (LDS_CB) {
+        const int n = K * d;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) s_cbT[i] = cbT[i];
+        __syncthreads();
+    }
+    for (uint32_t i0 = wave; i0 < count; i0 += 4 * nwaves) {
+        int64_t n[4];
+        uint32_t xv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t i = i0 + t * nwaves;
+            n[t] = (int64_t)queue[i < count ? i : count - 1];  // wave-uniform
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xv[t] = lane < d ? (uint32_t)blocks[(size_t)n[t] * d + lane] : 0u;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (i0 + t * nwaves >= count) break;
+            const uint8_t *xrow = blocks + (size_t)n[t] * d;
             int ri;
             double rd;
-            exact_search_wave(xrow, d, cbT, K, lane, ri, rd);
-            if (lane == src) {
-                labels[n] = ri;
-                if (min_dist) min_dist[n] = rd;
+            exact_search_wave<LDS_CB>(xv[t], xrow, d, cbT, s_cbT, K, lane, ri, rd);
+            if (lane == 0) {
+                labels[n[t]] = ri;
+                if (min_dist) min_dist[n[t]] = rd;
             }
             if (sums) {
                 for (int e = lane; e < d; e += WAVE) {
@@ -634,6 +749,7 @@ __device__ __forceinline__ double np_leaf_sum(const double *__restrict__ a, int 
 #pragma unroll
     for (int j = 0; j < 8; ++j) r[j] = a[j];
     int i = 8;
+#pragma unroll 4
     for (; i < n - (n % 8); i += 8) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) r[j] += a[i + j];
@@ -643,19 +759,36 @@ __device__ __forceinline__ double np_leaf_sum(const double *__restrict__ a, int 
     return res;
 }
 
-// One wave per full 8192-element chunk: lane l sums leaf l (128 elements) as numpy's unrolled
-// loop does; the recursive halving above the leaves is a balanced binary tree over adjacent
-// leaves, i.e. the xor-shuffle tree.  chunk_sums[c] receives the chunk's pairwise sum.
-__global__ __launch_bounds__(256) void k_npsum_chunks(const double *__restrict__ v, int64_t nfull,
+// One 512-thread workgroup per full 8192-element chunk.  A leaf is numpy's run of 128 elements:
+// eight interleaved partial sums r[j] = a[j] + a[8+j] + ... (16 terms, in order), combined as
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)).  Eight lanes own one leaf (lane j owns r[j]); the combine is
+// the xor-1,2,4 shuffle tree.  The recursive halving above the leaves is a balanced binary tree
+// over adjacent leaves: the xor tree over the 64 leaf sums.
+__global__ __launch_bounds__(512) void k_npsum_chunks(const double *__restrict__ v, int64_t nfull,
                                                       double *__restrict__ chunk_sums) {
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t c = wave; c < nfull; c += nwaves) {
-        double t = np_leaf_sum(v + c * NP_CHUNK + (int64_t)lane * 128, 128);
+    __shared__ double s_leaf[64];
+    const int tid = threadIdx.x;
+    const int j = tid & 7, leaf = tid >> 3;                    // 64 leaves x 8 lanes
+    for (int64_t c = blockIdx.x; c < nfull; c += gridDim.x) {
+        const double *a = v + c * NP_CHUNK + (int64_t)leaf * 128 + j;
+        double t[16];
 #pragma unroll
-        for (int off = 1; off < WAVE; off <<= 1) t += __shfl_xor(t, off, WAVE);
-        if (lane == 0) chunk_sums[c] = t;
+        for (int i = 0; i < 16; ++i) t[i] = a[8 * i];
+        double r = t[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) r += t[i];
+        r += __shfl_xor(r, 1, WAVE);
+        r += __shfl_xor(r, 2, WAVE);
+        r += __shfl_xor(r, 4, WAVE);
+        if (j == 0) s_leaf[leaf] = r;
+        __syncthreads();
+        if (tid < WAVE) {
+            double u = s_leaf[tid];
+#pragma unroll
+            for (int off = 1; off < WAVE; off <<= 1) u += __shfl_xor(u, off, WAVE);
+            if (tid == 0) chunk_sums[c] = u;
+        }
+        __syncthreads();
     }
 }
 
@@ -874,7 +1007,7 @@ int dp2_bucket(int d) {
     return -1;
 }
 
-constexpr int r_for(int dp2) { return dp2 <= 8 ? 4 : (dp2 <= 16 ? 4 : (dp2 <= 32 ? 2 : 1)); }
+constexpr int r_for(int dp2) { return dp2 <= 8 ? VQ_R8 : (dp2 <= 16 ? 4 : (dp2 <= 32 ? 2 : 1)); }
 
 int ceil_log2(int64_t v) {
     int b = 0;
@@ -947,7 +1080,7 @@ int run_prepare(const double *cb, int K, int d, void *ws, hipStream_t st) {
     const int dp2 = dp2_bucket(d);
     WsLayout L = ws_layout(K, d, 0);
     char *w = static_cast<char *>(ws);
-    const size_t hash_lds = (size_t)(K <= PREP_HASH_CAP ? K : 1) * sizeof(unsigned long long);
+    const size_t hash_lds = (K <= PREP_HASH_CAP && K > 1) ? (size_t)K * 32 : 16;   // 2K keys + K hashes + 2K indices
     if (hash_lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_prepare), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)hash_lds));
@@ -969,6 +1102,10 @@ int run_fast(const uint8_t *blocks, int64_t N, int d, const double *cb, int K, i
     uint32_t *c16 = reinterpret_cast<uint32_t *>(w + L.c16);
     uint32_t *bias = reinterpret_cast<uint32_t *>(w + L.bias);
     double *cbT = reinterpret_cast<double *>(w + L.cbT);
+    WsLayout LN = ws_layout(K, d, N);
+    uint32_t *qcount = reinterpret_cast<uint32_t *>(w + LN.qcount);
+    uint32_t *queue = reinterpret_cast<uint32_t *>(w + LN.queue);
+    HIP_TRY(hipMemsetAsync(qcount, 0, 256, st));
 
     DeviceInfo di;
     int rc = device_info(di);
@@ -991,20 +1128,28 @@ int run_fast(const uint8_t *blocks, int64_t N, int d, const double *cb, int K, i
     const int R = r_for(dp2);
     const int64_t tile = (int64_t)block * R;
     const int64_t ntiles = (N + tile - 1) / tile;
-    int wg_per_cu = block == 256 ? 8 : 4;
-    if (lds > 0) {
-        int by_lds = (int)((160 * 1024) / lds);
-        if (by_lds < 1) by_lds = 1;
-        if (by_lds < wg_per_cu) wg_per_cu = by_lds;
+    // Encode only: one tile per workgroup, so the dispatcher balances the chip and the last,
+    // partly filled round of workgroups runs at full clock (measured faster than any persistent
+    // grid).  LBG mode: a persistent grid, because every workgroup ends with a flush of its LDS
+    // table and fewer workgroups mean fewer global atomics.
+    int64_t max_grid = (int64_t)1 << 30;
+    if (sums) {
+        int wg_per_cu = block == 256 ? VQ_WG_PER_CU : 4;
+        if (lds > 0) {
+            int by_lds = (int)((160 * 1024) / lds);
+            if (by_lds < 1) by_lds = 1;
+            if (by_lds < wg_per_cu) wg_per_cu = by_lds;
+        }
+        max_grid = (int64_t)di.cus * wg_per_cu;
+        if (max_grid > MAX_GRID) max_grid = MAX_GRID;
     }
-    int64_t max_grid = (int64_t)di.cus * wg_per_cu;
-    if (max_grid > MAX_GRID) max_grid = MAX_GRID;
     int grid = (int)(ntiles < max_grid ? ntiles : max_grid);
     if (grid < 1) grid = 1;
 
     AssignArgs a;
     a.blocks = blocks; a.N = N; a.d = d; a.cb = cb; a.K = K; a.kbits = kbits; a.hdr = hdr;
     a.labels = labels; a.min_dist = min_dist; a.sums = sums; a.counts = counts;
+    a.queue = queue; a.qcount = qcount;
     a.acc_mode = acc_mode; a.ntiles = ntiles;
     a.vec4 = ((d & 3) == 0) && ((reinterpret_cast<uintptr_t>(blocks) & 3) == 0);
 
@@ -1023,9 +1168,19 @@ int run_fast(const uint8_t *blocks, int64_t N, int d, const double *cb, int K, i
         default: return fail(VQ_E_UNSUPPORTED, "no fast kernel for d=%d", d);
     }
     if (rc) return rc;
-    // fix-up: 64 labels per wave trip
-    int fgrid = grid_for((N + WAVE - 1) / WAVE, 4, di.cus * 8);
-    hipLaunchKernelGGL(k_fixup, dim3(fgrid), dim3(256), 0, st, blocks, N, d, cbT, K, labels, min_dist, sums, counts);
+    // fix-up: a fixed grid strides over the queue (its length is only known on the device); small
+    // codebooks are staged in LDS, one 1024-thread workgroup per CU
+    const size_t cb_bytes = (size_t)K * d * sizeof(double);
+    if (cb_bytes <= 64 * 1024) {
+        if (cb_bytes > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fixup<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)cb_bytes));
+        hipLaunchKernelGGL(k_fixup<true>, dim3(di.cus), dim3(1024), cb_bytes, st, blocks, d, cbT, K, queue, qcount,
+                           labels, min_dist, sums, counts);
+    } else {
+        hipLaunchKernelGGL(k_fixup<false>, dim3(di.cus * 4), dim3(256), 0, st, blocks, d, cbT, K, queue, qcount, labels,
+                           min_dist, sums, counts);
+    }
     LAUNCH_CHECK("k_fixup");
     return VQ_OK;
 }
@@ -1037,8 +1192,8 @@ int run_numpy_sum(const double *v, int64_t N, double *chunk_sums, double *out, h
         DeviceInfo di;
         int rc = device_info(di);
         if (rc) return rc;
-        int grid = grid_for(nfull, 4, di.cus * 8);
-        hipLaunchKernelGGL(k_npsum_chunks, dim3(grid), dim3(256), 0, st, v, nfull, chunk_sums);
+        int grid = grid_for(nfull, 1, di.cus * 8);
+        hipLaunchKernelGGL(k_npsum_chunks, dim3(grid), dim3(512), 0, st, v, nfull, chunk_sums);
         LAUNCH_CHECK("k_npsum_chunks");
     }
     hipLaunchKernelGGL(k_npsum_final, dim3(1), dim3(1024), 0, st, v, N, nfull, chunk_sums, out);
@@ -1107,7 +1262,8 @@ int vq_encode_l1(const uint8_t *blocks, int64_t N, int d, const double *cb, int 
     if (!labels) return fail(VQ_E_INVALID, "null labels pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (mode == VQ_MODE_FAST && fast_supported(d)) {
-        rc = check_ws(ws, ws_bytes, K, d, 0);
+        if (N > 0xfffffff0LL) return fail(VQ_E_UNSUPPORTED, "N=%lld exceeds 2^32 per call", (long long)N);
+        rc = check_ws(ws, ws_bytes, K, d, N);
         if (rc) return rc;
         rc = run_prepare(cb, K, d, ws, st);
         if (rc) return rc;
@@ -1135,7 +1291,8 @@ int vq_encode_l1_prepared(const uint8_t *blocks, int64_t N, int d, const double 
     int rc = check_common(blocks, N, d, cb, K);
     if (rc) return rc;
     if (!fast_supported(d)) return fail(VQ_E_UNSUPPORTED, "d=%d is beyond the prepared (fast) kernels", d);
-    rc = check_ws(ws, ws_bytes, K, d, 0);
+    if (N > 0xfffffff0LL) return fail(VQ_E_UNSUPPORTED, "N=%lld exceeds 2^32 per call", (long long)N);
+    rc = check_ws(ws, ws_bytes, K, d, N);
     if (rc) return rc;
     if (N == 0) return VQ_OK;
     if (!labels) return fail(VQ_E_INVALID, "null labels pointer");
@@ -1169,6 +1326,7 @@ int vq_lbg_accum(const uint8_t *blocks, int64_t N, int d, const double *cb, int 
     if (!sums || !counts || !dist_sum) return fail(VQ_E_INVALID, "null sums, counts or dist_sum pointer");
     if (N != 0 && (!labels || !min_dist)) return fail(VQ_E_INVALID, "null labels or min_dist pointer");
     if (mode != VQ_MODE_EXACT && mode != VQ_MODE_FAST) return fail(VQ_E_INVALID, "unknown mode %d", mode);
+    if (N > 0xfffffff0LL) return fail(VQ_E_UNSUPPORTED, "N=%lld exceeds 2^32 per call", (long long)N);
     rc = check_ws(ws, ws_bytes, K, d, N);
     if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -86,19 +86,19 @@ class HipEngine:
         K = cb.shape[0]
         labels = torch.empty(N, dtype=torch.int32, device=self.device)
         mind = torch.empty(N, dtype=torch.float64, device=self.device) if want_dist else None
-        ws = self._workspace(K, d)
+        ws = self._workspace(K, d, N)
         with torch.cuda.device(self.device):
             check(lib.vq_encode_l1(_ptr(blocks), N, d, _ptr(cb), K, _ptr(labels), _ptr(mind),
                                    self.mode if mode is None else mode, _ptr(ws), ws.numel(), self._stream()),
                   "vq_encode_l1")
         return (labels, mind) if want_dist else labels
 
-    def prepare_codebook(self, cb, d=None):
-        """Fill a private workspace for cb; returns a handle for encode_prepared (many batches, one
-        codebook)."""
+    def prepare_codebook(self, cb, max_vectors):
+        """Fill a private workspace for cb; returns a handle for encode_prepared (many batches of up
+        to max_vectors block vectors, one codebook)."""
         cb = self._dev(cb, torch.float64)
         K, d = cb.shape
-        need = lib.vq_workspace_bytes(int(K), int(d), 0)
+        need = lib.vq_workspace_bytes(int(K), int(d), int(max_vectors))
         ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
             check(lib.vq_codebook_prepare(_ptr(cb), K, d, _ptr(ws), ws.numel(), self._stream()),
