@@ -1,0 +1,69 @@
+"""The sharded LBG loop on the real HIP engine: two ranks (gloo rendezvous, both on cuda:0) each
+hold a shard of the block vectors; the exchange is the one bench.py and multi-GPU jobs use
+(all-reduce of integer sums/counts, all-gather of per-chunk distance sums).  The result must be
+bit-identical to the single-GPU run, including every distortion when the shards are 8192-aligned."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _make_blocks():
+    rng = np.random.default_rng(21)
+    base = rng.integers(0, 256, size=(40, 16))
+    idx = rng.integers(0, 40, size=3 * 8192 + 517)
+    noise = rng.integers(-6, 7, size=(len(idx), 16))
+    return np.clip(base[idx] + noise, 0, 255).astype(np.uint8)
+
+
+def _worker(rank, world, port, cut, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vector_quantization_amd import HipEngine, train_lbg
+        blocks = _make_blocks()
+        bounds = [0, cut, len(blocks)]
+        eng = HipEngine("cuda:0")
+        shard = torch.from_numpy(blocks[bounds[rank]:bounds[rank + 1]].copy()).to("cuda:0")
+        res = train_lbg(eng, shard, 32, group=dist.group.WORLD, log=None)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), codebook=res.codebook.cpu().numpy(),
+                 iters=np.array(res.iters_per_stage), dist=np.array(res.distortions))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cut", [8192, 2 * 8192, 10000])
+def test_two_ranks_equal_one_gpu(tmp_path, cut, oracle):
+    from vector_quantization_amd import HipEngine, train_lbg
+    blocks = _make_blocks()
+    single = train_lbg(HipEngine("cuda:0"), torch.from_numpy(blocks).to("cuda:0"), 32, log=None)
+    ref = oracle.lbg_train(blocks, 32)
+    assert np.array_equal(single.codebook.cpu().numpy(), ref["codebook"])
+    assert np.array_equal(np.array(single.distortions), ref["distortions"])
+    mp.spawn(_worker, args=(2, _free_port(), cut, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(r0["codebook"], r1["codebook"])
+    assert np.array_equal(r0["codebook"], single.codebook.cpu().numpy())
+    assert list(r0["iters"]) == single.iters_per_stage
+    if cut % 8192 == 0:
+        assert np.array_equal(r0["dist"], np.array(single.distortions))
+    else:
+        assert np.allclose(r0["dist"], np.array(single.distortions), rtol=1e-12, atol=0)

@@ -215,39 +215,69 @@ __device__ __forceinline__ void exact_search_wave(uint32_t xv0, const uint8_t *_
 // ------------------------------------------------------------------------------------------------
 // block extraction (VQ_Full.py:23-33, 51-57)
 // ------------------------------------------------------------------------------------------------
-// One thread per output byte group: G = 4 consecutive bytes when a block row segment (bw*C bytes)
-// is a multiple of 4, else 1.  Consecutive threads write consecutive bytes of the block matrix.
+// One thread per group of G consecutive bytes of the block matrix.  G = 16 (four 4-byte words,
+// one 16-byte store) or 4 when a block row segment (bw*C bytes) is a multiple of 4, else 1.  A
+// word that lies inside the image and is 4-byte aligned there is fetched with one load; words in
+// the padding (or in an image whose rows are not word-aligned) are assembled byte by byte.
 template <int G>
 __global__ __launch_bounds__(256) void k_blocks_u8(const uint8_t *__restrict__ img, int H, int W, int C, int bh,
                                                    int bw, int pad_zero, uint8_t *__restrict__ blocks, int nc,
-                                                   int64_t total_groups) {
+                                                   int64_t total_groups, int img_words_ok) {
     const int seg = bw * C;            // bytes of one block row segment
     const int d = bh * seg;
+    const int64_t rowbytes = (int64_t)W * C;
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total_groups;
          g += (int64_t)gridDim.x * blockDim.x) {
-        int64_t o = g * G;             // first output byte
-        int64_t n = o / d;
-        int e = (int)(o - n * d);
-        int r = (int)(n / nc), q = (int)(n - (int64_t)r * nc);
-        int i = e / seg, rem = e - i * seg;
-        int y = r * bh + i;
-        int yc = y < H ? y : H - 1;
-        uint8_t out[G];
-#pragma unroll
-        for (int t = 0; t < G; ++t) {
-            int j = (rem + t) / C, ch = (rem + t) - j * C;
+        const int64_t o = g * G;       // first output byte
+        if constexpr (G == 1) {
+            int64_t n = o / d;
+            int e = (int)(o - n * d);
+            int r = (int)(n / nc), q = (int)(n - (int64_t)r * nc);
+            int i = e / seg, rem = e - i * seg;
+            int y = r * bh + i;
+            int yc = y < H ? y : H - 1;
+            int j = rem / C, ch = rem - j * C;
             int x = q * bw + j;
             int xc = x < W ? x : W - 1;
             uint8_t v = img[((size_t)yc * W + xc) * C + ch];
             if (pad_zero && (y >= H || x >= W)) v = 0;
-            out[t] = v;
-        }
-        if (G == 4) {
-            uint32_t w = (uint32_t)out[0] | ((uint32_t)out[1 % G] << 8) | ((uint32_t)out[2 % G] << 16) |
-                         ((uint32_t)out[3 % G] << 24);
-            *reinterpret_cast<uint32_t *>(blocks + o) = w;
+            blocks[o] = v;
         } else {
-            blocks[o] = out[0];
+            constexpr int NW = G >= 4 ? G / 4 : 1;
+            uint32_t words[NW];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const int64_t ow = o + 4 * w;
+                int64_t n = ow / d;
+                int e = (int)(ow - n * d);
+                int r = (int)(n / nc), q = (int)(n - (int64_t)r * nc);
+                int i = e / seg, rem = e - i * seg;
+                int y = r * bh + i;
+                int yc = y < H ? y : H - 1;
+                int64_t xb = (int64_t)q * seg + rem;           // byte offset inside the (padded) image row
+                uint32_t v;
+                if (img_words_ok && xb + 4 <= rowbytes && (y < H || !pad_zero)) {
+                    v = *reinterpret_cast<const uint32_t *>(img + (size_t)yc * rowbytes + xb);
+                } else {
+                    v = 0;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        int j = (rem + t) / C, ch = (rem + t) - j * C;
+                        int x = q * bw + j;
+                        int xc = x < W ? x : W - 1;
+                        uint32_t b = img[((size_t)yc * W + xc) * C + ch];
+                        if (pad_zero && (y >= H || x >= W)) b = 0;
+                        v |= b << (8 * t);
+                    }
+                }
+                words[w] = v;
+            }
+            if (G == 16) {
+                uint4 out = make_uint4(words[0], words[1 % NW], words[2 % NW], words[3 % NW]);
+                *reinterpret_cast<uint4 *>(blocks + o) = out;
+            } else {
+                *reinterpret_cast<uint32_t *>(blocks + o) = words[0];
+            }
         }
     }
 }
@@ -935,26 +965,57 @@ __global__ __launch_bounds__(256) void k_cb_to_u8(const double *__restrict__ cb,
         out[i] = cast_u8(cb[i]);
 }
 
-// One thread per G output bytes of the image (G = 4 when a block row segment is a multiple of 4
-// bytes, else 1); consecutive threads write consecutive bytes of an image row.
-template <int G>
+// One thread per G consecutive output bytes of an image row: G = 16 (four 4-byte words gathered
+// from the truncated codebook, one 16-byte store) or 4 when a block row segment is a multiple of 4
+// bytes, else 1.  blockIdx.y strides over image rows, so all index arithmetic is 32-bit.  With
+// LDS_CB each workgroup truncates the fp64 codebook into LDS once (K*d bytes) and gathers from
+// there; otherwise it gathers from the uint8 copy that k_cb_to_u8 left in global memory.
+template <int G, bool LDS_CB>
 __global__ __launch_bounds__(256) void k_decode_u8(const int32_t *__restrict__ labels, int nr, int nc,
-                                                   const uint8_t *__restrict__ cb8, int bh, int bw, int C,
-                                                   uint8_t *__restrict__ img, int64_t total_groups) {
-    const int seg = bw * C;
-    const int d = bh * seg;
-    const int64_t rowbytes = (int64_t)nc * seg;
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total_groups;
-         g += (int64_t)gridDim.x * blockDim.x) {
-        int64_t o = g * G;
-        int64_t y = o / rowbytes;
-        int64_t xb = o - y * rowbytes;
-        int r = (int)(y / bh), i = (int)(y - (int64_t)r * bh);
-        int q = (int)(xb / seg), rem = (int)(xb - (int64_t)q * seg);
-        int k = labels[(size_t)r * nc + q];
-        const uint8_t *src = cb8 + (size_t)k * d + (size_t)i * seg + rem;
-        if (G == 4) *reinterpret_cast<uint32_t *>(img + o) = *reinterpret_cast<const uint32_t *>(src);
-        else img[o] = src[0];
+                                                   const double *__restrict__ cb, const uint8_t *__restrict__ cb8g,
+                                                   int K, int bh, int bw, int C, uint8_t *__restrict__ img) {
+    extern __shared__ __align__(16) uint8_t s_cb8[];
+    const uint32_t seg = (uint32_t)(bw * C);
+    const uint32_t d = (uint32_t)bh * seg;
+    const uint32_t rowbytes = (uint32_t)nc * seg;
+    const uint32_t groups_per_row = rowbytes / G;
+    const uint32_t rows = (uint32_t)nr * (uint32_t)bh;
+    if (LDS_CB) {
+        const uint32_t n = (uint32_t)K * d;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s_cb8[i] = cast_u8(cb[i]);
+        __syncthreads();
+    }
+    const uint8_t *cb8 = LDS_CB ? s_cb8 : cb8g;
+    for (uint32_t y = blockIdx.y; y < rows; y += gridDim.y) {
+        const uint32_t r = y / (uint32_t)bh, i = y - r * (uint32_t)bh;
+        const int32_t *lrow = labels + (size_t)r * nc;
+        uint8_t *orow = img + (size_t)y * rowbytes;
+        for (uint32_t xg = blockIdx.x * blockDim.x + threadIdx.x; xg < groups_per_row; xg += gridDim.x * blockDim.x) {
+            const uint32_t xb0 = xg * G;
+            if constexpr (G == 1) {
+                uint32_t q = xb0 / seg, rem = xb0 - q * seg;
+                orow[xb0] = cb8[(size_t)lrow[q] * d + i * seg + rem];
+            } else {
+                constexpr int NW = G >= 4 ? G / 4 : 1;
+                uint32_t words[NW];
+                uint32_t q = xb0 / seg, rem = xb0 - q * seg;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    words[w] = *reinterpret_cast<const uint32_t *>(cb8 + (size_t)lrow[q] * d + i * seg + rem);
+                    rem += 4;
+                    if (rem >= seg) {
+                        rem = 0;
+                        ++q;
+                    }
+                }
+                if (G == 16) {
+                    uint4 out = make_uint4(words[0], words[1 % NW], words[2 % NW], words[3 % NW]);
+                    *reinterpret_cast<uint4 *>(orow + xb0) = out;
+                } else {
+                    *reinterpret_cast<uint32_t *>(orow + xb0) = words[0];
+                }
+            }
+        }
     }
 }
 
@@ -1226,11 +1287,22 @@ int vq_blocks_u8(const uint8_t *img, int H, int W, int C, int bh, int bw, int pa
     int nr = (H + bh - 1) / bh, nc = (W + bw - 1) / bw;
     int64_t d = (int64_t)bh * bw * C;
     int64_t total = (int64_t)nr * nc * d;
-    bool g4 = ((bw * C) % 4 == 0) && ((reinterpret_cast<uintptr_t>(blocks) & 3) == 0);
-    int64_t groups = g4 ? total / 4 : total;
-    int grid = grid_for(groups, 256, 8192);
-    if (g4) hipLaunchKernelGGL(k_blocks_u8<4>, dim3(grid), dim3(256), 0, st, img, H, W, C, bh, bw, pad_mode == VQ_PAD_ZERO, blocks, nc, groups);
-    else hipLaunchKernelGGL(k_blocks_u8<1>, dim3(grid), dim3(256), 0, st, img, H, W, C, bh, bw, pad_mode == VQ_PAD_ZERO, blocks, nc, groups);
+    const uintptr_t optr = reinterpret_cast<uintptr_t>(blocks);
+    const int words_ok = (((int64_t)W * C) % 4 == 0) && ((reinterpret_cast<uintptr_t>(img) & 3) == 0);
+    const bool seg4 = (bw * C) % 4 == 0;
+    const int pz = pad_mode == VQ_PAD_ZERO;
+    if (seg4 && total % 16 == 0 && (optr & 15) == 0) {
+        int64_t groups = total / 16;
+        hipLaunchKernelGGL(k_blocks_u8<16>, dim3(grid_for(groups, 256, 16384)), dim3(256), 0, st, img, H, W, C, bh, bw, pz,
+                           blocks, nc, groups, words_ok);
+    } else if (seg4 && (optr & 3) == 0) {
+        int64_t groups = total / 4;
+        hipLaunchKernelGGL(k_blocks_u8<4>, dim3(grid_for(groups, 256, 16384)), dim3(256), 0, st, img, H, W, C, bh, bw, pz,
+                           blocks, nc, groups, words_ok);
+    } else {
+        hipLaunchKernelGGL(k_blocks_u8<1>, dim3(grid_for(total, 256, 16384)), dim3(256), 0, st, img, H, W, C, bh, bw, pz,
+                           blocks, nc, total, 0);
+    }
     LAUNCH_CHECK("k_blocks_u8");
     return VQ_OK;
 }
@@ -1385,15 +1457,45 @@ int vq_decode_u8(const int32_t *labels, int nr, int nc, const double *cb, int K,
     hipStream_t st = static_cast<hipStream_t>(stream);
     WsLayout L = ws_layout(K, d, 0);
     uint8_t *cb8 = reinterpret_cast<uint8_t *>(static_cast<char *>(ws) + L.cb_u8);
-    int64_t n = (int64_t)K * d;
-    hipLaunchKernelGGL(k_cb_to_u8, dim3(grid_for(n, 256, 4096)), dim3(256), 0, st, cb, n, cb8);
-    LAUNCH_CHECK("k_cb_to_u8");
-    int64_t total = (int64_t)nr * nc * d;
-    bool g4 = ((bw * C) % 4 == 0) && ((reinterpret_cast<uintptr_t>(img) & 3) == 0);
-    int64_t groups = g4 ? total / 4 : total;
-    int grid = grid_for(groups, 256, 8192);
-    if (g4) hipLaunchKernelGGL(k_decode_u8<4>, dim3(grid), dim3(256), 0, st, labels, nr, nc, cb8, bh, bw, C, img, groups);
-    else hipLaunchKernelGGL(k_decode_u8<1>, dim3(grid), dim3(256), 0, st, labels, nr, nc, cb8, bh, bw, C, img, groups);
+    const int64_t n = (int64_t)K * d;
+    const int64_t rowbytes = (int64_t)nc * bw * C;
+    if (rowbytes > 0x7fffffffLL || (int64_t)nr * bh > 0x7fffffffLL) return fail(VQ_E_UNSUPPORTED, "image too large");
+    const bool lds_cb = n <= 64 * 1024;
+    const size_t lds = lds_cb ? (size_t)((n + 15) / 16 * 16) : 0;
+    if (!lds_cb) {
+        hipLaunchKernelGGL(k_cb_to_u8, dim3(grid_for(n, 256, 4096)), dim3(256), 0, st, cb, n, cb8);
+        LAUNCH_CHECK("k_cb_to_u8");
+    }
+    const uintptr_t iptr = reinterpret_cast<uintptr_t>(img);
+    const bool seg4 = (bw * C) % 4 == 0;
+    const int G = (seg4 && rowbytes % 16 == 0 && (iptr & 15) == 0) ? 16 : ((seg4 && (iptr & 3) == 0) ? 4 : 1);
+    DeviceInfo di;
+    int rc2 = device_info(di);
+    if (rc2) return rc2;
+    // a fixed number of workgroups (each stages the codebook once) laid out as (x over a row, y over rows)
+    const int64_t groups_per_row = rowbytes / G;
+    int gx = grid_for(groups_per_row, 256, 64);
+    int64_t gy64 = ((int64_t)di.cus * 8 + gx - 1) / gx;
+    if (gy64 > (int64_t)nr * bh) gy64 = (int64_t)nr * bh;
+    if (gy64 > 65535) gy64 = 65535;
+    dim3 grid(gx, (unsigned)gy64);
+#define VQ_LAUNCH_DECODE(GG)                                                                                        \
+    do {                                                                                                            \
+        if (lds_cb) {                                                                                               \
+            if (lds > 48 * 1024)                                                                                    \
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_decode_u8<GG, true>),                  \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
+            hipLaunchKernelGGL((k_decode_u8<GG, true>), grid, dim3(256), lds, st, labels, nr, nc, cb, cb8, K, bh, bw, C, \
+                               img);                                                                                \
+        } else {                                                                                                    \
+            hipLaunchKernelGGL((k_decode_u8<GG, false>), grid, dim3(256), 0, st, labels, nr, nc, cb, cb8, K, bh, bw, C,  \
+                               img);                                                                                \
+        }                                                                                                           \
+    } while (0)
+    if (G == 16) VQ_LAUNCH_DECODE(16);
+    else if (G == 4) VQ_LAUNCH_DECODE(4);
+    else VQ_LAUNCH_DECODE(1);
+#undef VQ_LAUNCH_DECODE
     LAUNCH_CHECK("k_decode_u8");
     return VQ_OK;
 }

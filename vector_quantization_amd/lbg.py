@@ -25,10 +25,32 @@ def _group_size(group):
     return dist.get_world_size(group=group)
 
 
+def _needs_host_staging(t, group):
+    """gloo moves host memory; device tensors are staged through the host for it (RCCL takes them
+    as they are)."""
+    import torch.distributed as dist
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def _allreduce_sum_(t, group):
     import torch.distributed as dist
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    if _needs_host_staging(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
+
+
+def _allgather_to_host(t, group):
+    """All ranks' copies of t, stacked, as a host numpy array."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group=group)
+    src = t.cpu() if _needs_host_staging(t, group) else t
+    gathered = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(gathered, src, group=group)
+    return torch.stack(gathered).cpu().numpy()
 
 
 NP_CHUNK = 8192   # elements per pairwise-summed chunk of numpy's reduction (and of vq_numpy_sum_f64)
@@ -57,9 +79,7 @@ def _global_distance_sum(dist_sum, chunks, sizes, aligned, group):
         mine[: chunks.numel()] = chunks
     else:
         mine = dist_sum.reshape(1)
-    gathered = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(gathered, mine, group=group)
-    host = torch.stack(gathered).cpu().numpy()
+    host = _allgather_to_host(mine, group)
     if aligned:
         import numpy as np
         parts = [host[r, : -(-sizes[r] // NP_CHUNK)] for r in range(world)]
@@ -91,6 +111,7 @@ def lbg_iteration(engine, blocks, cb, n_total, group=None, shard_info=None):
     """One pass of VQ_Full.py:77-90.  Returns (new codebook, distortion as a Python float)."""
     if group is None:
         acc, dist = engine.lbg_accum(blocks, cb)
+        new_cb = engine.lbg_finalize(acc, cb)      # enqueued before the host waits for the distance sum
         total = float(dist.item())
     else:
         if shard_info is None:
@@ -98,8 +119,8 @@ def lbg_iteration(engine, blocks, cb, n_total, group=None, shard_info=None):
         aligned, sizes = shard_info
         acc, dist, chunks = engine.lbg_accum(blocks, cb, want_chunks=True)
         _allreduce_sum_(acc, group)
+        new_cb = engine.lbg_finalize(acc, cb)
         total = _global_distance_sum(dist, chunks, sizes, aligned, group)
-    new_cb = engine.lbg_finalize(acc, cb)
     return new_cb, total / float(n_total)
 
 
