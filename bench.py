@@ -137,12 +137,26 @@ def main():
     dec_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     ops = 2.0 * K_CODEBOOK * d * N                  # subtract + |.|-accumulate per (vector, codeword, element)
     achieved = ops / (enc_ms * 1e-3) / 1e12
-    roofline = dict(bound="valu", achieved=achieved, peak=PEAK_VALU_TOPS, unit="Top/s (non-FMA fp32-equivalent)",
-                    frac=achieved / PEAK_VALU_TOPS, traffic=None, kernel="k_assign_fast<8,4,packed>",
+    # HBM bytes per launch of the same kernel on the same workload, from separate rocprofv3 --pmc passes
+    # (FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as is); see profiles/
+    traffic, pmc_note = None, "no PMC summary found under profiles/"
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_encode_summary.json")
+    if os.path.isfile(pmc_path):
+        with open(pmc_path) as f:
+            pmc = json.load(f)
+        traffic = pmc["hbm_bytes_per_launch"]
+        pmc_note = (f"traffic and valu_busy_frac from profiles/r01_pmc_*.csv (rocprofv3 --pmc, same workload); "
+                    f"algorithmic bytes per launch = {N * (d + 4)}")
+    roofline = dict(bound="valu", achieved=achieved, peak=PEAK_VALU_TOPS, unit="TFLOP/s",
+                    frac=achieved / PEAK_VALU_TOPS, traffic=traffic,
+                    kernel="k_assign_fast<8,4,packed> + k_fixup (the two launches of vq_encode_l1_prepared)",
                     kernel_ms=enc_ms, algorithmic_ops_per_vector=2 * K_CODEBOOK * d,
                     algorithmic_bytes_per_vector=d + 4,
-                    note="integer v_sad_u16 retires two |x-c| accumulations per lane-instruction, so the "
-                         "algorithmic rate can exceed the fp32 non-FMA vector peak")
+                    valu_busy_frac=(pmc["valu_busy_frac"] if traffic is not None else None),
+                    note="ops = one subtract + one |.|-accumulate per (vector, codeword, element); peak = the fp32 "
+                         "vector peak counted without FMA (157.3 / 2). The integer v_sad_u16 retires two such "
+                         "pairs per lane-instruction, so frac can exceed 1; valu_busy_frac is the share of "
+                         "SIMD issue cycles the kernel's VALU instructions occupy. " + pmc_note)
     decode_gbs = (N * (d + 4)) / (dec_ms * 1e-3) / 1e9
 
     # ---- LBG iterations (fused assign + accumulate, exchange, centroid update) ----------------------

@@ -1,12 +1,7 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
-run() { echo "== $*"; env "$@" timeout -k 10 120 python3 tools/tune_variants.py 2>&1 | tail -1 | cut -c60-; }
 for rep in 1 2; do
-run A=1
-run VQ_TUNE_GRID=1000000 VQ_TUNE_GRID_LBG=1280
-run VQ_TUNE_GRID=1280 VQ_TUNE_GRID_LBG=1024
-run VQ_TUNE_BLOCK=1024 VQ_TUNE_GRID=256 VQ_TUNE_GRID_LBG=256
-run VQ_TUNE_BLOCK=512 VQ_TUNE_GRID=512 VQ_TUNE_GRID_LBG=512
-run VQ_TUNE_BLOCK=512 VQ_TUNE_GRID=1000000 VQ_TUNE_GRID_LBG=768
-run VQ_TUNE_BLOCK=1024 VQ_TUNE_GRID=1000000 VQ_TUNE_GRID_LBG=512
+for so in vector_quantization_amd/lib/libvqhip.so vector_quantization_amd/lib/variant_*.so; do
+  echo -n "$(basename $so) "; VQ_HIP_LIB=$PWD/$so timeout -k 10 120 python3 tools/tune_variants.py 2>&1 | tail -1 | cut -c60- || exit 1
+done
 done

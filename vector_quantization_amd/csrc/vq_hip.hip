@@ -76,6 +76,9 @@ constexpr int MAX_K = 1 << 20;
 #ifndef VQ_U8
 #define VQ_U8 4
 #endif
+#ifndef VQ_RBIG
+#define VQ_RBIG 2
+#endif
 #ifndef VQ_WG_PER_CU
 #define VQ_WG_PER_CU 8
 #endif
@@ -342,7 +345,7 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long h, unsign
 
 // Dynamic LDS: an open-addressing table of 2*K slots (keys = 64-bit row hashes), the K row hashes,
 // then per slot the smallest row index seen for its key.
-__global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb, int K, int d, int dp2,
+__global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb, int K, int d, int dp2, uint32_t clim,
                                                   PrepHeader *__restrict__ hdr, uint32_t *__restrict__ c16,
                                                   uint32_t *__restrict__ bias, double *__restrict__ cbT) {
     extern __shared__ __align__(16) unsigned long long s_keys[];
@@ -375,9 +378,13 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
     atomicMax(&s_cmax, lmax);
     __syncthreads();
     const uint32_t cmax = s_cmax;
+    // largest scale 2^s (s <= 8) that keeps both the pixels (<= 255) and the largest codebook entry
+    // within clim, the fixed-point limit the key layout allows
+    const uint64_t top = cmax > 255u ? cmax : 255u;
     int s = 8;
-    while (s > 0 && ((uint64_t)cmax << s) > 65535ull) --s;
+    while (s > 0 && (top << s) > (uint64_t)clim) --s;
     const double scale = (double)(1u << s);
+    const double qmax = (double)clim;
     // phase B: one thread per codeword: fixed-point row, rounding-error bound, transposed copy, row
     // hash.  The row is read eight entries at a time (loads first, arithmetic after).
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
@@ -404,7 +411,7 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
                             double t = cv * scale;
                             double q = rint(t);
                             if (!(q >= 0.0)) q = 0.0;          // also catches NaN
-                            if (q > 65535.0) q = 65535.0;
+                            if (q > qmax) q = qmax;
                             double de = fabs(t - q);
                             if (!(de == de)) de = 4.0e9;
                             err += de;
@@ -478,7 +485,7 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
 // ------------------------------------------------------------------------------------------------
 constexpr int ACC_NONE = 0;     // labels (+ distances) only
 constexpr int ACC_LDS = 1;      // cluster sums / counts through an LDS table, flushed with 64-bit atomics
-constexpr int ACC_GLOBAL = 2;   // cluster sums / counts straight to global 64-bit atomics
+                                // (tables beyond the LDS are served by k_accum_rows after the search)
 
 constexpr int KEY_PACKED = 0;   // key = (S << kbits) + (k | dupbit): needs S << kbits < 2^31
 constexpr int KEY_SPLIT = 1;    // value and index tracked separately
@@ -498,14 +505,25 @@ struct AssignArgs {
     unsigned long long *sums;   // ACC_*: (K, d)
     unsigned long long *counts; // ACC_*: (K)
     int acc_mode;
+    int tab_words;              // words of dynamic LDS in front of the codeword tiles (the ACC_LDS table, padded)
     int vec4;                   // rows may be read as aligned 32-bit words (d % 4 == 0, base 4-byte aligned)
     int64_t ntiles;
 };
 
-template <int DP2, int R, int KEYMODE>
-__global__ __launch_bounds__(1024) void k_assign_fast(const AssignArgs a, const uint32_t *__restrict__ c16,
+// Codewords per LDS tile of the LDS_CW variant (about 4 KB of fixed-point rows per tile).
+constexpr int tile_k_for(int dp2) { return dp2 <= 8 ? 128 : (dp2 <= 16 ? 64 : (dp2 <= 32 ? 32 : (dp2 <= 64 ? 16 : 8))); }
+
+// LDS_CW = false: codewords come through scalar loads (small codebooks that live in the scalar
+// cache).  LDS_CW = true: the workgroup stages the fixed-point codebook through LDS in
+// double-buffered tiles (wide vector loads, one barrier per tile) and every wave reads the rows
+// back as broadcast LDS reads; this serves large dimensions (a row no longer fits the scalar
+// registers) and codebooks far beyond the scalar cache.
+template <int DP2, int R, int KEYMODE, bool LDS_CW>
+__global__ __launch_bounds__(512) void k_assign_fast(const AssignArgs a, const uint32_t *__restrict__ c16,
                                                      const uint32_t *__restrict__ bias) {
-    extern __shared__ __align__(16) uint32_t s_tab[];   // ACC_LDS: K * (d + 1) words, [sums | count] per codeword
+    // dynamic LDS: [ACC_LDS table: K * (d + 1) words, [sums | count] per codeword, padded to 16 B]
+    //              [LDS_CW: 2 tiles of TILE_K * DP2 words][2 x TILE_K bias words]
+    extern __shared__ __align__(16) uint32_t s_tab[];
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int BLOCK = blockDim.x;
@@ -571,44 +589,146 @@ __global__ __launch_bounds__(1024) void k_assign_fast(const AssignArgs a, const 
             m2[r] = 0xffffffffu;
             bi[r] = 0;
         }
-        // Codewords are fetched by scalar loads (wave-uniform addresses) in batches of U, so that
-        // one scalar-memory wait is paid per U * R * (DP2 + 3) vector instructions.
-        constexpr int U = DP2 <= 8 ? VQ_U8 : (DP2 <= 16 ? 2 : 1);
-        auto step = [&](const uint32_t *cw, uint32_t b, int k) {
+        // fold one codeword's SAD sums into the two smallest keys of each vector
+        auto finish = [&](const uint32_t *acc, uint32_t b, int k) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                uint32_t acc = 0;
-#pragma unroll
-                for (int p = 0; p < DP2; ++p) acc = __builtin_amdgcn_sad_u16(x[r][p], cw[p], acc);
                 if (KEYMODE == KEY_PACKED) {
-                    uint32_t key = (acc << kbits_v) + b;
+                    uint32_t key = (acc[r] << kbits_v) + b;
                     m2[r] = umed3(key, m1[r], m2[r]);
                     m1[r] = min(key, m1[r]);
                 } else {
-                    uint32_t v = acc + ((b >> 31) << 30);      // duplicate rows never compete
+                    uint32_t v = acc[r] + ((b >> 31) << 30);   // duplicate rows never compete
                     m2[r] = umed3(v, m1[r], m2[r]);
                     bi[r] = (v < m1[r]) ? (uint32_t)k : bi[r];
                     m1[r] = min(v, m1[r]);
                 }
             }
         };
-        int k = 0;
-        for (; k + U <= K; k += U) {
-            uint32_t cw[U][DP2], b[U];
+        auto step = [&](const uint32_t *cw, uint32_t b, int k) {
+            uint32_t acc[R];
 #pragma unroll
-            for (int j = 0; j < U; ++j) {
+            for (int r = 0; r < R; ++r) {
+                acc[r] = 0;
 #pragma unroll
-                for (int p = 0; p < DP2; ++p) cw[j][p] = c16[(size_t)(k + j) * DP2 + p];
-                b[j] = bias[k + j];
+                for (int p = 0; p < DP2; ++p) acc[r] = __builtin_amdgcn_sad_u16(x[r][p], cw[p], acc[r]);
             }
+            finish(acc, b, k);
+        };
+        if constexpr (!LDS_CW) {
+            // Codewords are fetched by scalar loads (wave-uniform addresses) in batches of U, so that
+            // one scalar-memory wait is paid per U * R * (DP2 + 3) vector instructions.
+            constexpr int U = DP2 <= 8 ? VQ_U8 : (DP2 <= 16 ? 2 : 1);
+            int k = 0;
+            for (; k + U <= K; k += U) {
+                uint32_t cw[U][DP2], b[U];
 #pragma unroll
-            for (int j = 0; j < U; ++j) step(cw[j], b[j], k + j);
-        }
-        for (; k < K; ++k) {
-            uint32_t cw[DP2];
+                for (int j = 0; j < U; ++j) {
 #pragma unroll
-            for (int p = 0; p < DP2; ++p) cw[p] = c16[(size_t)k * DP2 + p];
-            step(cw, bias[k], k);
+                    for (int p = 0; p < DP2; ++p) cw[j][p] = c16[(size_t)(k + j) * DP2 + p];
+                    b[j] = bias[k + j];
+                }
+#pragma unroll
+                for (int j = 0; j < U; ++j) step(cw[j], b[j], k + j);
+            }
+            for (; k < K; ++k) {
+                uint32_t cw[DP2];
+#pragma unroll
+                for (int p = 0; p < DP2; ++p) cw[p] = c16[(size_t)k * DP2 + p];
+                step(cw, bias[k], k);
+            }
+        } else {
+            constexpr int TILE_K = tile_k_for(DP2);
+            constexpr int TILE_W = TILE_K * DP2;               // words of fixed-point rows per tile
+            constexpr int NV = TILE_W / 4;                     // 16-byte pieces per tile
+            constexpr int MAXL = (NV + 255) / 256;             // pieces per thread (workgroups have >= 256 threads)
+            uint32_t *s_cw = s_tab + a.tab_words;
+            uint32_t *s_b = s_cw + 2 * TILE_W;
+            const int ntk = (K + TILE_K - 1) / TILE_K;
+            const uint32_t total_w = (uint32_t)K * DP2;
+            const uint4 *c16v = reinterpret_cast<const uint4 *>(c16);
+            uint4 pre[MAXL];
+            uint32_t preb = 0;
+            // rows past the end of the codebook are staged as zeros with the never-competes bias
+            auto gload = [&](int t) {
+#pragma unroll
+                for (int l = 0; l < MAXL; ++l) {
+                    const int i = tid + l * BLOCK;
+                    const uint32_t w0 = (uint32_t)t * TILE_W + (uint32_t)i * 4;
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (i < NV && w0 < total_w) v = c16v[w0 >> 2];
+                    if (w0 + 1 >= total_w) v.y = 0;
+                    if (w0 + 2 >= total_w) v.z = 0;
+                    if (w0 + 3 >= total_w) v.w = 0;
+                    pre[l] = v;
+                }
+                const int kk = t * TILE_K + tid;
+                preb = (tid < TILE_K && kk < K) ? bias[kk] : 0x80000000u;
+            };
+            auto lstore = [&](int t) {
+                uint4 *dst = reinterpret_cast<uint4 *>(s_cw + (t & 1) * TILE_W);
+#pragma unroll
+                for (int l = 0; l < MAXL; ++l) {
+                    const int i = tid + l * BLOCK;
+                    if (i < NV) dst[i] = pre[l];
+                }
+                if (tid < TILE_K) s_b[(t & 1) * TILE_K + tid] = preb;
+            };
+            uint32_t vz = 0;
+            asm volatile("" : "+v"(vz));
+            __syncthreads();                                   // the previous vector tile is done with the buffers
+            gload(0);
+            lstore(0);
+            __syncthreads();
+            for (int t = 0; t < ntk; ++t) {
+                if (t + 1 < ntk) gload(t + 1);
+                // vz is an opaque per-lane zero: it keeps the compiler from treating these (wave-uniform)
+                // LDS reads as scalar values, which it would move to scalar registers one
+                // v_readfirstlane at a time
+                const uint32_t *cwbuf = s_cw + (t & 1) * TILE_W + vz;
+                const uint32_t *bbuf = s_b + (t & 1) * TILE_K + vz;
+                if constexpr (DP2 <= 16) {
+#pragma unroll 2
+                    for (int kk = 0; kk < TILE_K; ++kk) {
+                        uint32_t cw[DP2];
+#pragma unroll
+                        for (int p = 0; p < DP2; ++p) cw[p] = cwbuf[kk * DP2 + p];
+                        step(cw, bbuf[kk], t * TILE_K + kk);
+                    }
+                } else {
+                    // long rows: read the row in chunks of CH words, one chunk ahead of the SADs that
+                    // use it, so that only two chunks of the row are in registers at a time
+                    constexpr int CH = 8;
+                    constexpr int NCH = DP2 / CH;
+                    for (int kk = 0; kk < TILE_K; ++kk) {
+                        const uint32_t *rowp = cwbuf + kk * DP2;
+                        uint32_t acc[R];
+#pragma unroll
+                        for (int r = 0; r < R; ++r) acc[r] = 0;
+                        uint32_t cur[CH], nxt[CH];
+#pragma unroll
+                        for (int p = 0; p < CH; ++p) cur[p] = rowp[p];
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) {
+                            if (c + 1 < NCH) {
+#pragma unroll
+                                for (int p = 0; p < CH; ++p) nxt[p] = rowp[(c + 1) * CH + p];
+                            }
+#pragma unroll
+                            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                                for (int p = 0; p < CH; ++p) acc[r] = __builtin_amdgcn_sad_u16(x[r][c * CH + p], cur[p], acc[r]);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int p = 0; p < CH; ++p) cur[p] = nxt[p];
+                        }
+                        finish(acc, bbuf[kk], t * TILE_K + kk);
+                    }
+                }
+                if (t + 1 < ntk) lstore(t + 1);
+                __syncthreads();
+            }
         }
         // ---- decide, measure, write, accumulate ----
 #pragma unroll
@@ -666,17 +786,6 @@ __global__ __launch_bounds__(1024) void k_assign_fast(const AssignArgs a, const 
                     }
                 }
                 atomicAdd(&t[d], 1u);
-            } else if (acc_mode == ACC_GLOBAL) {
-                unsigned long long *t = a.sums + (size_t)idx * d;
-#pragma unroll
-                for (int p = 0; p < DP2; ++p) {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        int e = 2 * p + h;
-                        if (e < d) atomicAdd(&t[e], (unsigned long long)((x[r][p] >> (s + 16 * h)) & 0xffu));
-                    }
-                }
-                atomicAdd(&a.counts[idx], 1ull);
             }
         }
         // 32-bit LDS sums hold 255 * (vectors per workgroup): flush long before they can wrap
@@ -908,9 +1017,7 @@ __global__ __launch_bounds__(1024) void k_npsum_final(const double *__restrict__
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_assign_exact(const uint8_t *__restrict__ blocks, int64_t N, int d,
                                                       const double *__restrict__ cb, int K,
-                                                      int32_t *__restrict__ labels, double *__restrict__ min_dist,
-                                                      unsigned long long *__restrict__ sums,
-                                                      unsigned long long *__restrict__ counts) {
+                                                      int32_t *__restrict__ labels, double *__restrict__ min_dist) {
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
         const uint8_t *x = blocks + (size_t)n * d;
         double best = __builtin_huge_val();
@@ -926,34 +1033,35 @@ __global__ __launch_bounds__(256) void k_assign_exact(const uint8_t *__restrict_
         }
         if (labels) labels[n] = bidx;
         if (min_dist) min_dist[n] = best;
-        if (sums) {
-            for (int e = 0; e < d; ++e) {
-                unsigned v = x[e];
-                if (v) atomicAdd(&sums[(size_t)bidx * d + e], (unsigned long long)v);
-            }
-            atomicAdd(&counts[bidx], 1ull);
-        }
     }
 }
 
-// Per-cluster sums / counts for given labels: straight 64-bit atomics (vq_accum_labels; not on the
-// fast path).
-__global__ __launch_bounds__(256) void k_accum_labels(const uint8_t *__restrict__ blocks, int64_t N, int d,
-                                                      const int32_t *__restrict__ labels, int K,
-                                                      unsigned long long *__restrict__ sums,
-                                                      unsigned long long *__restrict__ counts) {
-    const int64_t total = N * (int64_t)(d + 1);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t n = i / (d + 1);
-        int e = (int)(i - n * (d + 1));
-        int k = labels[n];
+// Per-cluster sums / counts for given labels, with coalesced atomics: a wave takes V = max(1, 64/d)
+// vectors per trip, lane (v, e) adds byte e of vector v to sums[label_v * d + e], so that one
+// wave-instruction adds to runs of d consecutive 64-bit words.  Serves vq_accum_labels and the
+// codebooks whose [K][d+1] table does not fit the LDS.
+__global__ __launch_bounds__(256) void k_accum_rows(const uint8_t *__restrict__ blocks, int64_t N, int d,
+                                                    const int32_t *__restrict__ labels, int K,
+                                                    unsigned long long *__restrict__ sums,
+                                                    unsigned long long *__restrict__ counts) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int V = d >= WAVE ? 1 : WAVE / d;
+    const int v = d >= WAVE ? 0 : lane / d;
+    const int e0 = d >= WAVE ? lane : lane - v * d;
+    const bool lane_on = d >= WAVE || v < V;
+    for (int64_t n0 = wave * V; n0 < N; n0 += nwaves * V) {
+        const int64_t n = n0 + v;
+        if (!lane_on || n >= N) continue;
+        const int k = labels[n];
         if ((unsigned)k >= (unsigned)K) continue;
-        if (e < d) {
-            unsigned v = blocks[(size_t)n * d + e];
-            if (v) atomicAdd(&sums[(size_t)k * d + e], (unsigned long long)v);
-        } else {
-            atomicAdd(&counts[k], 1ull);
+        const uint8_t *x = blocks + (size_t)n * d;
+        for (int e = e0; e < d; e += WAVE) {
+            unsigned b = x[e];
+            if (b) atomicAdd(&sums[(size_t)k * d + e], (unsigned long long)b);
         }
+        if (e0 == 0) atomicAdd(&counts[k], 1ull);
     }
 }
 
@@ -1068,7 +1176,7 @@ int dp2_bucket(int d) {
     return -1;
 }
 
-constexpr int r_for(int dp2) { return dp2 <= 8 ? VQ_R8 : (dp2 <= 16 ? 4 : (dp2 <= 32 ? 2 : 1)); }
+constexpr int r_for(int dp2) { return dp2 <= 8 ? VQ_R8 : (dp2 <= 16 ? 4 : VQ_RBIG); }
 
 int ceil_log2(int64_t v) {
     int b = 0;
@@ -1083,11 +1191,14 @@ int grid_for(int64_t work_items, int block, int max_blocks) {
     return (int)g;
 }
 
-template <int DP2, int KEYMODE>
+// Vectors per lane: the scalar-load variant serves d <= 32, the LDS variant everything.
+constexpr int r_lds_for(int dp2) { return dp2 <= 32 ? 4 : 2; }
+
+template <int DP2, int KEYMODE, bool LDS_CW>
 int launch_assign_fast_t(const AssignArgs &a, const uint32_t *c16, const uint32_t *bias, int block, int grid,
                          size_t lds, hipStream_t st) {
-    constexpr int R = r_for(DP2);
-    auto kern = k_assign_fast<DP2, R, KEYMODE>;
+    constexpr int R = LDS_CW ? r_lds_for(DP2) : r_for(DP2);
+    auto kern = k_assign_fast<DP2, R, KEYMODE, LDS_CW>;
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
@@ -1097,13 +1208,23 @@ int launch_assign_fast_t(const AssignArgs &a, const uint32_t *c16, const uint32_
 }
 
 template <int DP2>
-int launch_assign_fast_k(const AssignArgs &a, const uint32_t *c16, const uint32_t *bias, bool packed, int block,
-                         int grid, size_t lds, hipStream_t st) {
-    if constexpr (DP2 <= 32) {
-        if (packed) return launch_assign_fast_t<DP2, KEY_PACKED>(a, c16, bias, block, grid, lds, st);
+int launch_assign_fast_k(const AssignArgs &a, const uint32_t *c16, const uint32_t *bias, bool packed, bool lds_cw,
+                         int block, int grid, size_t lds, hipStream_t st) {
+    if constexpr (DP2 <= 16) {
+        if (!lds_cw) {
+            if (packed) return launch_assign_fast_t<DP2, KEY_PACKED, false>(a, c16, bias, block, grid, lds, st);
+            return launch_assign_fast_t<DP2, KEY_SPLIT, false>(a, c16, bias, block, grid, lds, st);
+        }
     }
-    return launch_assign_fast_t<DP2, KEY_SPLIT>(a, c16, bias, block, grid, lds, st);
+    if constexpr (DP2 <= 32) {
+        if (packed) return launch_assign_fast_t<DP2, KEY_PACKED, true>(a, c16, bias, block, grid, lds, st);
+    }
+    return launch_assign_fast_t<DP2, KEY_SPLIT, true>(a, c16, bias, block, grid, lds, st);
 }
+
+// The scalar-load variant is used while the fixed-point codebook (K * dp2 words) stays within
+// about twice the scalar cache and a row fits the scalar registers comfortably.
+bool use_lds_codewords(int K, int dp2) { return dp2 > 16 || (size_t)K * dp2 * 4 > 32 * 1024; }
 
 struct DeviceInfo {
     int cus;
@@ -1119,6 +1240,29 @@ int device_info(DeviceInfo &di) {
     di.cus = cus;
     di.lds_per_block = (size_t)lds;
     return VQ_OK;
+}
+
+// Key layout of the filter.  Packed keys hold (S << kbits) + index in 31 bits, so the SAD sum S of
+// 2*dp2 terms, each at most clim, must stay below 2^(31 - kbits); clim is the fixed-point limit the
+// prepare kernel scales codebook and pixels into.  Packed is used when that still leaves at least
+// 4 fractional bits for 8-bit data; otherwise value and index are tracked separately (clim 65535).
+struct KeyLayout {
+    bool packed;
+    uint32_t clim;
+};
+
+KeyLayout key_layout(int K, int dp2) {
+    const int kbits = ceil_log2(K);
+    KeyLayout kl{false, 65535u};
+    if (dp2 <= 32 && kbits < 31) {
+        uint64_t lim = ((1ull << (31 - kbits)) - 1) / (2ull * dp2);
+        if (lim > 65535) lim = 65535;
+        if (lim >= 255ull * 16) {
+            kl.packed = true;
+            kl.clim = (uint32_t)lim;
+        }
+    }
+    return kl;
 }
 
 int check_common(const void *blocks, int64_t N, int d, const void *cb, int K) {
@@ -1145,7 +1289,8 @@ int run_prepare(const double *cb, int K, int d, void *ws, hipStream_t st) {
     if (hash_lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_prepare), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)hash_lds));
-    hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1024), hash_lds, st, cb, K, d, dp2, reinterpret_cast<PrepHeader *>(w + L.header),
+    hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1024), hash_lds, st, cb, K, d, dp2, key_layout(K, dp2).clim,
+                       reinterpret_cast<PrepHeader *>(w + L.header),
                        reinterpret_cast<uint32_t *>(w + L.c16), reinterpret_cast<uint32_t *>(w + L.bias),
                        reinterpret_cast<double *>(w + L.cbT));
     LAUNCH_CHECK("k_prepare");
@@ -1173,20 +1318,24 @@ int run_fast(const uint8_t *blocks, int64_t N, int d, const double *cb, int K, i
     if (rc) return rc;
 
     const int kbits = ceil_log2(K);
-    // packed keys need (max SAD sum) << kbits to stay below 2^31
-    const uint64_t smax = (uint64_t)dp2 * 2ull * 65535ull;
-    const bool packed = dp2 <= 32 && ((smax << kbits) < (1ull << 31));
+    const bool packed = key_layout(K, dp2).packed;
 
     int acc_mode = ACC_NONE;
     size_t lds = 0;
     int block = 256;
+    bool rows_pass = false;      // accumulate in a separate coalesced pass (table too large for the LDS)
     if (sums) {
         size_t tab = (size_t)K * (d + 1) * 4;
         if (tab <= 40 * 1024) { acc_mode = ACC_LDS; lds = tab; block = 256; }
         else if (tab <= di.lds_per_block) { acc_mode = ACC_LDS; lds = tab; block = 512; }
-        else { acc_mode = ACC_GLOBAL; }
+        else { rows_pass = true; }
     }
-    const int R = r_for(dp2);
+    unsigned long long *ksums = rows_pass ? nullptr : sums;       // what the search kernels accumulate into
+    unsigned long long *kcounts = rows_pass ? nullptr : counts;
+    const bool lds_cw = use_lds_codewords(K, dp2);
+    const int R = lds_cw ? r_lds_for(dp2) : r_for(dp2);
+    const size_t tab_bytes = (lds + 15) / 16 * 16;
+    if (lds_cw) lds = tab_bytes + (size_t)2 * tile_k_for(dp2) * (dp2 + 1) * 4;
     const int64_t tile = (int64_t)block * R;
     const int64_t ntiles = (N + tile - 1) / tile;
     // Encode only: one tile per workgroup, so the dispatcher balances the chip and the last,
@@ -1194,7 +1343,7 @@ int run_fast(const uint8_t *blocks, int64_t N, int d, const double *cb, int K, i
     // grid).  LBG mode: a persistent grid, because every workgroup ends with a flush of its LDS
     // table and fewer workgroups mean fewer global atomics.
     int64_t max_grid = (int64_t)1 << 30;
-    if (sums) {
+    if (acc_mode == ACC_LDS) {
         int wg_per_cu = block == 256 ? VQ_WG_PER_CU : 4;
         if (lds > 0) {
             int by_lds = (int)((160 * 1024) / lds);
@@ -1209,23 +1358,23 @@ int run_fast(const uint8_t *blocks, int64_t N, int d, const double *cb, int K, i
 
     AssignArgs a;
     a.blocks = blocks; a.N = N; a.d = d; a.cb = cb; a.K = K; a.kbits = kbits; a.hdr = hdr;
-    a.labels = labels; a.min_dist = min_dist; a.sums = sums; a.counts = counts;
+    a.labels = labels; a.min_dist = min_dist; a.sums = ksums; a.counts = kcounts;
     a.queue = queue; a.qcount = qcount;
-    a.acc_mode = acc_mode; a.ntiles = ntiles;
+    a.acc_mode = acc_mode; a.ntiles = ntiles; a.tab_words = (int)(tab_bytes / 4);
     a.vec4 = ((d & 3) == 0) && ((reinterpret_cast<uintptr_t>(blocks) & 3) == 0);
 
     switch (dp2) {
-        case 2:  rc = launch_assign_fast_k<2>(a, c16, bias, packed, block, grid, lds, st); break;
-        case 4:  rc = launch_assign_fast_k<4>(a, c16, bias, packed, block, grid, lds, st); break;
-        case 6:  rc = launch_assign_fast_k<6>(a, c16, bias, packed, block, grid, lds, st); break;
-        case 8:  rc = launch_assign_fast_k<8>(a, c16, bias, packed, block, grid, lds, st); break;
-        case 12: rc = launch_assign_fast_k<12>(a, c16, bias, packed, block, grid, lds, st); break;
-        case 16: rc = launch_assign_fast_k<16>(a, c16, bias, packed, block, grid, lds, st); break;
-        case 24: rc = launch_assign_fast_k<24>(a, c16, bias, packed, block, grid, lds, st); break;
-        case 32: rc = launch_assign_fast_k<32>(a, c16, bias, packed, block, grid, lds, st); break;
-        case 48: rc = launch_assign_fast_k<48>(a, c16, bias, packed, block, grid, lds, st); break;
-        case 64: rc = launch_assign_fast_k<64>(a, c16, bias, packed, block, grid, lds, st); break;
-        case 96: rc = launch_assign_fast_k<96>(a, c16, bias, packed, block, grid, lds, st); break;
+        case 2:  rc = launch_assign_fast_k<2>(a, c16, bias, packed, lds_cw, block, grid, lds, st); break;
+        case 4:  rc = launch_assign_fast_k<4>(a, c16, bias, packed, lds_cw, block, grid, lds, st); break;
+        case 6:  rc = launch_assign_fast_k<6>(a, c16, bias, packed, lds_cw, block, grid, lds, st); break;
+        case 8:  rc = launch_assign_fast_k<8>(a, c16, bias, packed, lds_cw, block, grid, lds, st); break;
+        case 12: rc = launch_assign_fast_k<12>(a, c16, bias, packed, lds_cw, block, grid, lds, st); break;
+        case 16: rc = launch_assign_fast_k<16>(a, c16, bias, packed, lds_cw, block, grid, lds, st); break;
+        case 24: rc = launch_assign_fast_k<24>(a, c16, bias, packed, lds_cw, block, grid, lds, st); break;
+        case 32: rc = launch_assign_fast_k<32>(a, c16, bias, packed, lds_cw, block, grid, lds, st); break;
+        case 48: rc = launch_assign_fast_k<48>(a, c16, bias, packed, lds_cw, block, grid, lds, st); break;
+        case 64: rc = launch_assign_fast_k<64>(a, c16, bias, packed, lds_cw, block, grid, lds, st); break;
+        case 96: rc = launch_assign_fast_k<96>(a, c16, bias, packed, lds_cw, block, grid, lds, st); break;
         default: return fail(VQ_E_UNSUPPORTED, "no fast kernel for d=%d", d);
     }
     if (rc) return rc;
@@ -1237,12 +1386,18 @@ int run_fast(const uint8_t *blocks, int64_t N, int d, const double *cb, int K, i
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fixup<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)cb_bytes));
         hipLaunchKernelGGL(k_fixup<true>, dim3(di.cus), dim3(1024), cb_bytes, st, blocks, d, cbT, K, queue, qcount,
-                           labels, min_dist, sums, counts);
+                           labels, min_dist, ksums, kcounts);
     } else {
         hipLaunchKernelGGL(k_fixup<false>, dim3(di.cus * 4), dim3(256), 0, st, blocks, d, cbT, K, queue, qcount, labels,
-                           min_dist, sums, counts);
+                           min_dist, ksums, kcounts);
     }
     LAUNCH_CHECK("k_fixup");
+    if (rows_pass) {
+        const int V = d >= WAVE ? 1 : WAVE / d;
+        hipLaunchKernelGGL(k_accum_rows, dim3(grid_for((N + V - 1) / V, 4, 16384)), dim3(256), 0, st, blocks, N, d, labels,
+                           K, sums, counts);
+        LAUNCH_CHECK("k_accum_rows");
+    }
     return VQ_OK;
 }
 
@@ -1342,8 +1497,7 @@ int vq_encode_l1(const uint8_t *blocks, int64_t N, int d, const double *cb, int 
         return run_fast(blocks, N, d, cb, K, labels, min_dist, nullptr, nullptr, ws, st);
     }
     int grid = grid_for(N, 256, 16384);
-    hipLaunchKernelGGL(k_assign_exact, dim3(grid), dim3(256), 0, st, blocks, N, d, cb, K, labels, min_dist,
-                       (unsigned long long *)nullptr, (unsigned long long *)nullptr);
+    hipLaunchKernelGGL(k_assign_exact, dim3(grid), dim3(256), 0, st, blocks, N, d, cb, K, labels, min_dist);
     LAUNCH_CHECK("k_assign_exact");
     return VQ_OK;
 }
@@ -1377,10 +1531,11 @@ int vq_accum_labels(const uint8_t *blocks, int64_t N, int d, const int32_t *labe
     if (N == 0) return VQ_OK;
     if (!blocks || !labels || !sums || !counts) return fail(VQ_E_INVALID, "null pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    int grid = grid_for(N * (int64_t)(d + 1), 256, 16384);
-    hipLaunchKernelGGL(k_accum_labels, dim3(grid), dim3(256), 0, st, blocks, N, d, labels, K,
+    const int V = d >= WAVE ? 1 : WAVE / d;
+    int grid = grid_for((N + V - 1) / V, 4, 16384);
+    hipLaunchKernelGGL(k_accum_rows, dim3(grid), dim3(256), 0, st, blocks, N, d, labels, K,
                        reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts));
-    LAUNCH_CHECK("k_accum_labels");
+    LAUNCH_CHECK("k_accum_rows");
     return VQ_OK;
 }
 
@@ -1412,8 +1567,12 @@ int vq_lbg_accum(const uint8_t *blocks, int64_t N, int d, const double *cb, int 
             if (rc) return rc;
         } else {
             int grid = grid_for(N, 256, 16384);
-            hipLaunchKernelGGL(k_assign_exact, dim3(grid), dim3(256), 0, st, blocks, N, d, cb, K, labels, min_dist, s64, c64);
+            hipLaunchKernelGGL(k_assign_exact, dim3(grid), dim3(256), 0, st, blocks, N, d, cb, K, labels, min_dist);
             LAUNCH_CHECK("k_assign_exact");
+            const int V = d >= WAVE ? 1 : WAVE / d;
+            hipLaunchKernelGGL(k_accum_rows, dim3(grid_for((N + V - 1) / V, 4, 16384)), dim3(256), 0, st, blocks, N, d,
+                               labels, K, s64, c64);
+            LAUNCH_CHECK("k_accum_rows");
         }
     }
     double *cs = chunk_sums ? chunk_sums
