@@ -245,5 +245,24 @@ def main():
                         means=np.array([np.mean(a) for a in arrs]))
 
 
+def gray_case():
+    """old/CodeBook_VQ.py (grayscale, zero padding) run unmodified on man.jpeg, 4x4 blocks, k=16."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_gray", os.path.join(REF, "old", "CodeBook_VQ.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = tempfile.mkdtemp(prefix="vqgold_")
+    jp = os.path.join(out, "cb.json")
+    stdout = io.StringIO()
+    with contextlib.redirect_stdout(stdout):
+        cb = mod.Codebook(os.path.join(REF, "man.jpeg"), 4, 4)
+        cb.generate_codebook(16, json_path=jp)
+    gray = np.array(Image.open(os.path.join(REF, "man.jpeg")).convert("L"))
+    np.savez_compressed(os.path.join(HERE, "gray_man_4x4_k16.npz"), gray=gray, blocks=cb.blocks, codebook=cb.codebook,
+                        json_text=open(jp).read(), log=stdout.getvalue())
+    print("gray_man_4x4_k16:", cb.blocks.shape, cb.codebook.shape)
+
+
 if __name__ == "__main__":
     main()
+    gray_case()

@@ -103,6 +103,21 @@ def test_encode_codebook_sizes(eng, oracle, K):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("K,d", [(300, 48), (70, 48), (130, 192), (1030, 16), (3000, 12), (33, 64), (4096, 3)])
+def test_encode_ragged_codebook_tiles(eng, oracle, K, d):
+    """Codebook sizes that are not a multiple of the codeword batch / LDS tile of their kernel variant."""
+    rng = np.random.default_rng(K * 1000 + d)
+    N = 4099
+    cb = rng.random((K, d)) * 255.0
+    pick = rng.integers(0, K, N)
+    blocks = np.clip(cb[pick] + rng.normal(0, 12, (N, d)), 0, 255).astype(np.uint8)
+    want_l, want_d = oracle.encode_l1(blocks, cb, want_dist=True)
+    got_l, got_d = eng.encode(dev(blocks), dev(cb), want_dist=True, mode=1)
+    assert np.array_equal(got_l.cpu().numpy(), want_l)
+    assert np.array_equal(got_d.cpu().numpy(), want_d)
+    assert len(np.unique(want_l)) > min(K, 30) // 2          # the labels really spread over the codebook
+
+
 def test_encode_ties_and_duplicates(eng, oracle):
     """Exact ties: duplicated codewords, integer codewords equidistant from integer pixels, and a
     flat image; the lowest index must win, as numpy.argmin does."""
@@ -294,6 +309,32 @@ def test_codebook_class_matches_reference(tmp_path, train_case, mode, capsys):
     assert hashlib.sha256(open(cb.codebook_txt, "rb").read()).hexdigest() == str(g["codebook_txt_sha256"])
     arr = Codebook.decompress(cb.labels_json, cb.codebook_json, cb.reconstructed_path, device="cuda:0")
     assert arr.dtype == np.uint8 and np.array_equal(arr, g["decoded"])
+
+
+def test_gray_codebook_class_matches_old_reference(tmp_path, capsys):
+    """GrayCodebook on the GPU against old/CodeBook_VQ.py run unmodified (grayscale, zero padding)."""
+    from vector_quantization_amd import GrayCodebook
+    from vqtest_util import load_golden
+    g = load_golden("gray_man_4x4_k16")
+    cb = GrayCodebook("unused", 4, 4, device="cuda:0", image=g["gray"])
+    assert np.array_equal(cb.blocks, g["blocks"])
+    jp = tmp_path / "cb.json"
+    cb.generate_codebook(16, json_path=str(jp))
+    assert capsys.readouterr().out == str(g["log"])
+    assert np.array_equal(cb.codebook, g["codebook"])
+    assert open(jp).read() == str(g["json_text"])
+
+
+def test_decompress_crop(tmp_path):
+    from vector_quantization_amd import Codebook
+    from vqtest_util import load_golden
+    g = load_golden("synth_gray_250x246_4x4_k64")
+    cb = Codebook.from_array(g["img"], 4, 4, base_name="s", device="cuda:0", output_dir=str(tmp_path))
+    cb.generate_codebook(int(g["k"]))
+    cb.compress()
+    crop = Codebook.decompress(cb.labels_json, cb.codebook_json, cb.reconstructed_path, device="cuda:0",
+                               crop=(cb.orig_h, cb.orig_w))
+    assert np.array_equal(crop, g["decoded"][:250, :246])
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -145,3 +145,48 @@ def test_forced_iteration_counts(engine):
 def test_final_codebook_size():
     from vector_quantization_amd import final_codebook_size
     assert [final_codebook_size(k) for k in (1, 2, 3, 5, 8, 9, 256, 257)] == [1, 2, 4, 8, 8, 16, 256, 512]
+
+
+def test_gray_codebook_matches_old_reference_class(tmp_path, engine, capsys):
+    """GrayCodebook against old/CodeBook_VQ.py run unmodified (golden gray_man_4x4_k16): zero padding,
+    printed lines, codebook bit for bit, JSON text byte for byte."""
+    from vector_quantization_amd import GrayCodebook
+    g = load_golden("gray_man_4x4_k16")
+    cb = GrayCodebook("unused", 4, 4, engine=engine, image=g["gray"])
+    assert cb.blocks.dtype == np.uint8 and np.array_equal(cb.blocks, g["blocks"])
+    jp = tmp_path / "cb.json"
+    out_list = cb.generate_codebook(16, json_path=str(jp))
+    assert capsys.readouterr().out == str(g["log"])
+    assert np.array_equal(cb.codebook, g["codebook"])
+    assert open(jp).read() == str(g["json_text"])
+    assert np.array(out_list).shape == (16, 4, 4)
+    with pytest.raises(ValueError, match="k is larger than number of blocks!"):
+        cb.generate_codebook(len(cb.blocks) + 1, json_path=str(jp))
+
+
+def test_gray_codebook_opens_file_as_luminance(tmp_path, engine):
+    from PIL import Image
+    from vector_quantization_amd import GrayCodebook
+    rgb = np.random.default_rng(3).integers(0, 256, (10, 7, 3), dtype=np.uint8)
+    p = tmp_path / "c.png"
+    Image.fromarray(rgb).save(p)
+    cb = GrayCodebook(str(p), 4, 4, engine=engine)
+    lum = np.array(Image.open(p).convert("L"))
+    padded = np.pad(lum, ((0, 2), (0, 1)), mode="constant", constant_values=0)
+    want = padded.reshape(3, 4, 2, 4).swapaxes(1, 2).reshape(-1, 16)
+    assert np.array_equal(cb.blocks, want)
+
+
+def test_decompress_crop_option(tmp_path, engine):
+    from vector_quantization_amd import Codebook
+    g = load_golden("synth_gray_250x246_4x4_k64")
+    cb = Codebook.from_array(g["img"], 4, 4, base_name="s", engine=engine, output_dir=str(tmp_path))
+    cb.generate_codebook(int(g["k"]))
+    cb.compress()
+    full = Codebook.decompress(cb.labels_json, cb.codebook_json, cb.reconstructed_path, engine=engine)
+    assert np.array_equal(full, g["decoded"])                       # default: padded size, as the reference
+    crop = Codebook.decompress(cb.labels_json, cb.codebook_json, cb.reconstructed_path, engine=engine,
+                               crop=(cb.orig_h, cb.orig_w))
+    assert crop.shape[:2] == (250, 246) and np.array_equal(crop, full[:250, :246])
+    from PIL import Image
+    assert Image.open(cb.reconstructed_path).size == (246, 250)

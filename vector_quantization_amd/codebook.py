@@ -163,9 +163,10 @@ class Codebook:
 
     # -- decode (VQ_Full.py:153-172) ------------------------------------------------------------------------
     @staticmethod
-    def decompress(labels_path, codebook_path, output_path, *, device=None, engine=None):
+    def decompress(labels_path, codebook_path, output_path, *, device=None, engine=None, crop=None):
         """Called on the class, as the reference's (self-less) method is: shapes come from the two
-        JSON files only."""
+        JSON files only.  crop=(orig_h, orig_w) cuts the padding off the result (the reference never
+        crops, VQ_Full.py:169; old/Fatma_CodeBook_VQ.py:105 shows the intended crop); default off."""
         with open(labels_path) as f:
             labels = np.array(json.load(f))
         with open(codebook_path) as f:
@@ -177,6 +178,8 @@ class Codebook:
         cb_dev = torch.from_numpy(np.ascontiguousarray(codebook, dtype=np.float64).reshape(len(codebook), -1)).to(
             eng.device)
         arr = eng.decode(lab_dev, cb_dev, block_h, block_w, channels).cpu().numpy()
+        if crop is not None:
+            arr = np.ascontiguousarray(arr[: int(crop[0]), : int(crop[1])])
         from PIL import Image
         if channels == 3:
             Image.fromarray(arr).save(output_path)

@@ -125,13 +125,14 @@ def lbg_iteration(engine, blocks, cb, n_total, group=None, shard_info=None):
 
 
 def train_lbg(engine, blocks, k, epsilon=0.01, threshold=0.001, max_iterations=100, group=None, log=print,
-              iters_per_stage=None):
+              iters_per_stage=None, on_converged=None):
     """Follows VQ_Full.py:60-98.
 
     blocks: this rank's (N_local, d) uint8 shard on the engine's device.  group: a
     torch.distributed process group when the vectors are sharded (None = single GPU).
     iters_per_stage: optional list forcing the number of iterations of each stage (parity runs
     "given the same iteration count"); the stop rule is then not consulted.
+    on_converged(size, i, distortion): called instead of `log` when a stage meets the stop rule.
     """
     centroid, n_total = initial_centroid(engine, blocks, group)
     if k > n_total:
@@ -157,7 +158,9 @@ def train_lbg(engine, blocks, k, epsilon=0.01, threshold=0.001, max_iterations=1
                 change = abs(prev - distortion) / prev if prev != 0.0 else float("nan")
                 if change < threshold:
                     conv_i = i
-                    if log is not None:
+                    if on_converged is not None:
+                        on_converged(int(cb.shape[0]), i, distortion)
+                    elif log is not None:
                         log(f"Converged at iter {i}, distortion={distortion:.3f}")
                     break
             prev = distortion
