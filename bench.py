@@ -101,9 +101,15 @@ def main():
     prepared = eng.prepare_codebook(cb, blocks.shape[0])
     labels = torch.empty(N, dtype=torch.int32, device=device)
     nr, nc = H // BH, W // BW
+    sorted_buf = eng.sort_blocks(blocks)                                 # allocated once, refilled every step
+
+    def encode():
+        # the window sort is part of the encode: the step starts from the plain block matrix
+        srt = eng.sort_blocks(blocks, out=sorted_buf)
+        eng.encode_prepared(blocks, prepared, labels=labels, sorted=srt)
 
     def step():
-        eng.encode_prepared(blocks, prepared, labels=labels)
+        encode()
         return eng.decode(labels.view(nr, nc), cb, BH, BW, 1)
 
     for _ in range(args.warmup):
@@ -124,10 +130,19 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     for a, b in ev:
         a.record()
-        eng.encode_prepared(blocks, prepared, labels=labels)
+        encode()
         b.record()
     torch.cuda.synchronize(device)
     enc_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    labels_pruned = labels.clone()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for a, b in ev:
+        a.record()
+        eng.encode_prepared(blocks, prepared, labels=labels)              # every codeword for every vector
+        b.record()
+    torch.cuda.synchronize(device)
+    enc_full_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    full_equals_pruned = bool(torch.equal(labels, labels_pruned))
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     for a, b in ev:
         a.record()
@@ -149,26 +164,36 @@ def main():
                     f"algorithmic bytes per launch = {N * (d + 4)}")
     roofline = dict(bound="valu", achieved=achieved, peak=PEAK_VALU_TOPS, unit="TFLOP/s",
                     frac=achieved / PEAK_VALU_TOPS, traffic=traffic,
-                    kernel="k_assign_fast<8,4,packed> + k_fixup (the two launches of vq_encode_l1_prepared)",
-                    kernel_ms=enc_ms, algorithmic_ops_per_vector=2 * K_CODEBOOK * d,
+                    kernel="k_window_sort + k_assign_fast<8,4,packed,pruned> + k_fixup (vq_blocks_sort + "
+                           "vq_encode_l1_prepared)",
+                    kernel_ms=enc_ms, full_search_ms=enc_full_ms,
+                    full_search_achieved=ops / (enc_full_ms * 1e-3) / 1e12,
+                    full_search_frac=ops / (enc_full_ms * 1e-3) / 1e12 / PEAK_VALU_TOPS,
+                    full_search_labels_equal=full_equals_pruned,
+                    algorithmic_ops_per_vector=2 * K_CODEBOOK * d,
                     algorithmic_bytes_per_vector=d + 4,
                     valu_busy_frac=(pmc["valu_busy_frac"] if traffic is not None else None),
                     note="ops = one subtract + one |.|-accumulate per (vector, codeword, element); peak = the fp32 "
                          "vector peak counted without FMA (157.3 / 2). The integer v_sad_u16 retires two such "
                          "pairs per lane-instruction, so frac can exceed 1; valu_busy_frac is the share of "
-                         "SIMD issue cycles the kernel's VALU instructions occupy. " + pmc_note)
+                         "SIMD issue cycles the kernel's VALU instructions occupy. The timed encode sorts each "
+                         "window of 8192 vectors by element sum and skips codewords whose element sum is "
+                         "provably too far (|sum x - sum c| <= L1 distance), so it evaluates only part of the "
+                         "K*N pairs while returning the same labels; full_search_* is the same launch pair "
+                         "without that pruning. " + pmc_note)
     decode_gbs = (N * (d + 4)) / (dec_ms * 1e-3) / 1e9
 
     # ---- LBG iterations (fused assign + accumulate, exchange, centroid update) ----------------------
     n_total = world * N
     cur = cb
     for _ in range(2):
-        cur, _ = lbg_iteration(eng, blocks, cur, n_total, group)
+        cur, _ = lbg_iteration(eng, blocks, cur, n_total, group, sorted=sorted_buf)
     barrier()
     t0 = time.perf_counter()
     lbg_steps = max(5, args.steps // 2)
     for _ in range(lbg_steps):
-        cur, _ = lbg_iteration(eng, blocks, cur, n_total, group)
+        # the vectors do not change between iterations: the sort made above serves all of them
+        cur, _ = lbg_iteration(eng, blocks, cur, n_total, group, sorted=sorted_buf)
     barrier()
     lbg_elapsed = time.perf_counter() - t0
     t = torch.tensor([lbg_elapsed], dtype=torch.float64, device=device)

@@ -70,13 +70,27 @@ int vq_colsum_u8(const uint8_t *blocks, int64_t N, int d, uint64_t *sums, void *
 int vq_encode_l1(const uint8_t *blocks, int64_t N, int d, const double *cb, int K,
                  int32_t *labels, double *min_dist, int mode, void *ws, size_t ws_bytes, void *stream);
 
+/* Window-sorted copy of the block vectors, the input of the pruned search.  No counterpart in the
+ * reference: it is a second layout of self.blocks (VQ_Full.py:51-57), built once per image and
+ * reused by every LBG iteration (VQ_Full.py:77) and by compress (VQ_Full.py:124).  Inside every window of 8192
+ * consecutive vectors the rows are reordered by element sum; `sorted` (vq_sorted_bytes(d, N) bytes,
+ * 16-byte aligned) receives the reordered rows and, per row, where in its window it came from.
+ * Passing it to vq_encode_l1_prepared / vq_lbg_accum lets the search skip every codeword whose
+ * element sum differs from the vector's by more than the best distance found (a lower bound of
+ * the L1 distance), with identical results.  vq_prune_supported(K, d) tells whether a (K, d)
+ * codebook is served by that search (else `sorted` is ignored). */
+size_t vq_sorted_bytes(int d, int64_t N);
+int vq_prune_supported(int K, int d);
+int vq_blocks_sort(const uint8_t *blocks, int64_t N, int d, void *sorted, size_t sorted_bytes, void *stream);
+
 /* The same search split in two, for callers that encode many batches with one codebook (a batch of
  * images, repeated benchmark steps): vq_codebook_prepare fills ws from cb once (one small launch),
  * vq_encode_l1_prepared then runs VQ_MODE_FAST's two kernels (filter, fp64 fix-up) per batch.  ws must not
  * be handed to any other call in between; cb must still hold the same codebook.  Only dimensions
- * d <= 192 (the SAD filter kernels) are served; others return VQ_E_UNSUPPORTED. */
+ * d <= 192 (the SAD filter kernels) are served; others return VQ_E_UNSUPPORTED.  `sorted` is null
+ * or the buffer vq_blocks_sort filled from the same blocks. */
 int vq_codebook_prepare(const double *cb, int K, int d, void *ws, size_t ws_bytes, void *stream);
-int vq_encode_l1_prepared(const uint8_t *blocks, int64_t N, int d, const double *cb, int K,
+int vq_encode_l1_prepared(const uint8_t *blocks, const void *sorted, int64_t N, int d, const double *cb, int K,
                           int32_t *labels, double *min_dist, void *ws, size_t ws_bytes, void *stream);
 
 /* One LBG assignment pass, fused.  Replaces VQ_Full.py:77-90 up to the division: assigns every
@@ -87,8 +101,9 @@ int vq_encode_l1_prepared(const uint8_t *blocks, int64_t N, int d, const double 
  * into, so the caller zeroes them first (and may all-reduce them across GPUs afterwards).
  * chunk_sums (nullable) receives the ceil(N / 8192) per-chunk sums dist_sum is the left-to-right
  * total of; ranks that hold consecutive, 8192-aligned shards can concatenate them to reproduce
- * the single-process value. */
-int vq_lbg_accum(const uint8_t *blocks, int64_t N, int d, const double *cb, int K,
+ * the single-process value.  `sorted` is null or the buffer vq_blocks_sort filled from the same
+ * blocks (used by VQ_MODE_FAST only). */
+int vq_lbg_accum(const uint8_t *blocks, const void *sorted, int64_t N, int d, const double *cb, int K,
                  uint64_t *sums, uint64_t *counts, int32_t *labels, double *min_dist, double *dist_sum,
                  double *chunk_sums, int mode, void *ws, size_t ws_bytes, void *stream);
 

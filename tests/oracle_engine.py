@@ -23,13 +23,16 @@ class OracleEngine:
     def colsum(self, blocks):
         return torch.from_numpy(o.colsum_u8(blocks.numpy()).astype(np.int64))
 
-    def encode(self, blocks, cb, want_dist=False, mode=None):
+    def sort_blocks(self, blocks, out=None):
+        return None          # a layout of the device path only; the search result does not depend on it
+
+    def encode(self, blocks, cb, want_dist=False, mode=None, sorted=None):
         labels, mind = o.encode_l1(blocks.numpy(), cb.numpy(), want_dist=True)
         if want_dist:
             return torch.from_numpy(labels), torch.from_numpy(mind)
         return torch.from_numpy(labels)
 
-    def lbg_accum(self, blocks, cb, want_labels=False, mode=None, want_chunks=False):
+    def lbg_accum(self, blocks, cb, want_labels=False, mode=None, want_chunks=False, sorted=None):
         b = blocks.numpy()
         K, d = cb.shape
         N = b.shape[0]

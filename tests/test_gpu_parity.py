@@ -279,6 +279,103 @@ def test_numpy_order_sum(eng, oracle):
 
 
 # ---------------------------------------------------------------------------------------------------
+# window-sorted vectors + pruned search: identical results to the full search
+# ---------------------------------------------------------------------------------------------------
+def _sorted_parts(buf, N, d):
+    """(rows, perm) views of the buffer vq_blocks_sort fills: N*d row bytes, padded to 256, then N uint16."""
+    off = (N * d + 255) // 256 * 256
+    h = buf.cpu().numpy()
+    return h[: N * d].reshape(N, d), h[off: off + 2 * N].view(np.uint16)
+
+
+@pytest.mark.parametrize("N,d", [(1, 16), (100, 16), (8192, 16), (8193, 16), (30000, 16), (20001, 4), (9000, 27), (17000, 32),
+                                 (8500, 48)])
+def test_sort_blocks_is_a_windowed_permutation(eng, N, d):
+    rng = np.random.default_rng(N + d)
+    base = rng.integers(0, 200, size=(N, 1))
+    blocks = np.clip(base + rng.integers(0, 56, size=(N, d)), 0, 255).astype(np.uint8)
+    buf = eng.sort_blocks(dev(blocks))
+    rows, perm = _sorted_parts(buf, N, d)
+    shift = 0
+    while (255 * d) >> shift >= 2048:
+        shift += 1
+    for w0 in range(0, N, 8192):
+        n = min(8192, N - w0)
+        p = perm[w0: w0 + n].astype(np.int64)
+        assert np.array_equal(np.sort(p), np.arange(n))                        # a permutation inside the window
+        assert np.array_equal(rows[w0: w0 + n], blocks[w0 + p])               # rows moved with their origin
+        key = rows[w0: w0 + n].astype(np.int64).sum(1) >> shift
+        assert np.all(np.diff(key) >= 0)                                       # ascending element-sum buckets
+
+
+def _pruned_case(eng, oracle, blocks, cb, want_dist=True):
+    want_l, want_d = oracle.encode_l1(blocks, cb, want_dist=True)
+    b = dev(blocks)
+    srt = eng.sort_blocks(b)
+    got_l, got_d = eng.encode(b, dev(cb), want_dist=True, mode=1, sorted=srt)
+    assert np.array_equal(got_l.cpu().numpy(), want_l)
+    assert np.array_equal(got_d.cpu().numpy(), want_d)
+
+
+@pytest.mark.parametrize("K,d,N", [(32, 16, 5000), (64, 4, 20000), (255, 16, 9000), (256, 16, 40000), (1000, 16, 8192),
+                                   (1024, 16, 12000), (2048, 4, 9000), (100, 27, 7000), (128, 32, 10000), (40, 12, 3000),
+                                   (300, 8, 16385)])
+def test_encode_pruned_structured(eng, oracle, K, d, N):
+    """Vectors and codewords with a wide spread of element sums (where pruning really skips rows)."""
+    assert eng.prune_supported(K, d)
+    rng = np.random.default_rng(K * 7 + d)
+    cb = np.clip(rng.random((K, 1)) * 255.0 + rng.normal(0, 20, (K, d)), 0, 300)
+    pick = rng.integers(0, K, N)
+    blocks = np.clip(cb[pick] + rng.normal(0, 10, (N, d)), 0, 255).astype(np.uint8)
+    _pruned_case(eng, oracle, blocks, cb)
+
+
+@pytest.mark.parametrize("K,d", [(256, 16), (64, 8)])
+def test_encode_pruned_adversarial(eng, oracle, K, d):
+    """No spread at all (iid vectors, codewords with equal sums), duplicate and all-zero codewords,
+    codewords far outside the pixel range: the pruned search must fall back to the whole codebook."""
+    rng = np.random.default_rng(K + d)
+    N = 10000
+    blocks = rng.integers(0, 256, size=(N, d), dtype=np.uint8)
+    cb = rng.random((K, d)) * 255.0
+    cb *= (127.5 * d / cb.sum(1))[:, None]                       # equal element sums
+    _pruned_case(eng, oracle, blocks, cb)
+    cb2 = rng.random((K, d)) * 255.0
+    cb2[5] = cb2[3]; cb2[K - 1] = cb2[3]; cb2[7] = 0.0; cb2[8] = 0.0; cb2[9] = 257.55; cb2[10] = 1000.0
+    blocks[:500] = 0
+    blocks[500:900] = 255
+    _pruned_case(eng, oracle, blocks, cb2)
+
+
+def test_encode_pruned_golden(eng, oracle, train_case):
+    g = train_case
+    K, d = g["codebook"].shape
+    if not eng.prune_supported(K, d):
+        pytest.skip("codebook shape is not served by the pruned search")
+    b = dev(g["blocks"])
+    got = eng.encode(b, dev(g["codebook"]), mode=1, sorted=eng.sort_blocks(b)).cpu().numpy()
+    assert np.array_equal(got.reshape(g["labels"].shape), g["labels"])
+
+
+@pytest.mark.parametrize("K,d", [(256, 16), (64, 4), (1024, 16), (2048, 16)])
+def test_lbg_iteration_pruned(eng, oracle, K, d):
+    rng = np.random.default_rng(K * 3 + d)
+    N = 20000
+    cb = np.clip(rng.random((K, 1)) * 255.0 + rng.normal(0, 25, (K, d)), 0, 255)
+    blocks = np.clip(cb[rng.integers(0, K, N)] + rng.normal(0, 12, (N, d)), 0, 255).astype(np.uint8)
+    blocks[:3000] = blocks[0]
+    want = oracle.lbg_iter(blocks, cb)
+    b = dev(blocks)
+    acc, dist, labels = eng.lbg_accum(b, dev(cb), want_labels=True, mode=1, sorted=eng.sort_blocks(b))
+    acc_h = acc.cpu().numpy().astype(np.uint64)
+    assert np.array_equal(labels.cpu().numpy(), want["labels"])
+    assert np.array_equal(acc_h[: K * d].reshape(K, d), want["sums"])
+    assert np.array_equal(acc_h[K * d:], want["counts"])
+    assert dist.item() == oracle.numpy_sum(want["min_dist"])
+
+
+
+# ---------------------------------------------------------------------------------------------------
 # full training, through the reference-shaped Codebook class
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("mode", ["fast", "exact"])
@@ -395,6 +492,10 @@ def test_full_size_encode_decode_properties(eng, oracle):
     lab_fast = eng.encode(blocks, cb, mode=1)
     lab_exact = eng.encode(blocks, cb, mode=0)
     assert torch.equal(lab_fast, lab_exact)                       # filter + re-check == all-fp64 search
+    srt = eng.sort_blocks(blocks)
+    lab_pruned, mind_pruned = eng.encode(blocks, cb, mode=1, sorted=srt, want_dist=True)
+    assert torch.equal(lab_pruned, lab_exact)                     # pruned search == all-fp64 search
+    acc_p, dist_p = eng.lbg_accum(blocks, cb, sorted=srt)
     # a sample against the CPU oracle
     idx = torch.randperm(blocks.shape[0], device="cuda:0")[:20000]
     want = oracle.encode_l1(blocks[idx].cpu().numpy(), cb.cpu().numpy())
@@ -422,3 +523,4 @@ def test_full_size_encode_decode_properties(eng, oracle):
     assert torch.equal(acc, acc2) and dist.item() == dist2.item() and torch.equal(lab2, lab_fast)
     _, mind = eng.encode(blocks, cb, want_dist=True)
     assert dist.item() == float(np.add.reduce(mind.cpu().numpy()))
+    assert torch.equal(mind, mind_pruned) and torch.equal(acc, acc_p) and dist.item() == dist_p.item()

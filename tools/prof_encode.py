@@ -20,12 +20,18 @@ cb = train_lbg(eng, crop, 256, log=None).codebook
 prepared = eng.prepare_codebook(cb, blocks.shape[0])
 labels = torch.empty(blocks.shape[0], dtype=torch.int32, device=dev)
 torch.cuda.synchronize()
+srt = eng.sort_blocks(blocks)
 for _ in range(reps):
-    eng.encode_prepared(blocks, prepared, labels=labels)
+    eng.encode_prepared(blocks, prepared, labels=labels)                 # full search
+for _ in range(reps):
+    srt = eng.sort_blocks(blocks, out=srt)
+    eng.encode_prepared(blocks, prepared, labels=labels, sorted=srt)     # window sort + pruned search
 for _ in range(reps):
     eng.decode(labels.view(2048, 2048), cb, 4, 4, 1)
 for _ in range(reps):
     eng.lbg_accum(blocks, cb)
+for _ in range(reps):
+    eng.lbg_accum(blocks, cb, sorted=srt)
 for _ in range(reps):
     eng.blocks_from_image(img, 4, 4)
 torch.cuda.synchronize()

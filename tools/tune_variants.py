@@ -28,4 +28,20 @@ for a, b in ev:
     a.record(); eng.lbg_accum(blocks, cb); b.record()
 torch.cuda.synchronize()
 t2 = [a.elapsed_time(b) * 1e3 for a, b in ev]
+srt = eng.sort_blocks(blocks)
+def timeit(fn, n=30):
+    for _ in range(3):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    t = [a.elapsed_time(b) * 1e3 for a, b in ev]
+    return statistics.median(t), min(t)
+lab2 = torch.empty_like(labels)
+p_enc = timeit(lambda: eng.encode_prepared(blocks, prepared, labels=lab2, sorted=srt))
+p_sort = timeit(lambda: eng.sort_blocks(blocks, out=srt))
+p_lbg = timeit(lambda: eng.lbg_accum(blocks, cb, sorted=srt))
+ok = bool(torch.equal(lab2, labels))
+print(f"PRUNED encode med {p_enc[0]:7.1f} min {p_enc[1]:7.1f} | sort med {p_sort[0]:6.1f} | lbg_accum med {p_lbg[0]:7.1f} min {p_lbg[1]:7.1f} same={ok} || ", end="")
 print(f"{os.environ.get('VQ_HIP_LIB', 'default'):60s} encode med {statistics.median(t):7.1f} min {min(t):7.1f} us | lbg_accum med {statistics.median(t2):7.1f} min {min(t2):7.1f} us  checksum {int(labels.sum().item())}")

@@ -78,6 +78,7 @@ class Codebook:
         img_dev = torch.from_numpy(np.ascontiguousarray(self.img_arr)).to(self._engine.device)
         self._blocks_dev = self._engine.blocks_from_image(img_dev, block_h, block_w, pad_mode)
         self._blocks_host = None
+        self._blocks_sorted = None
         self._img_padded = None
         self._codebook_dev = None
         self.codebook = None
@@ -110,6 +111,13 @@ class Codebook:
     def image_to_blocks(self):
         return self.blocks
 
+    def _sorted_blocks(self):
+        """Second device layout of the block matrix (windows sorted by element sum) that lets the
+        search skip codewords; built on first use, shared by training and compress."""
+        if self._blocks_sorted is None:
+            self._blocks_sorted = self._engine.sort_blocks(self._blocks_dev)
+        return self._blocks_sorted
+
     # -- training (VQ_Full.py:60-117) -------------------------------------------------------------------
     def generate_codebook(self, k, epsilon=0.01, threshold=0.001, max_iterations=100, *, iters_per_stage=None):
         n_local = self._blocks_dev.shape[0]
@@ -119,7 +127,8 @@ class Codebook:
             )
         print(f"\n=== Starting LBG for k={k} ===")
         res = _lbg.train_lbg(self._engine, self._blocks_dev, k, epsilon, threshold, max_iterations,
-                             group=self._group, log=print, iters_per_stage=iters_per_stage)
+                             group=self._group, log=print, iters_per_stage=iters_per_stage,
+                             sorted=self._sorted_blocks())
         self._codebook_dev = res.codebook
         self.codebook = res.codebook.cpu().numpy()
         self.training = res
@@ -147,7 +156,7 @@ class Codebook:
         if self._codebook_dev is None:                       # codebook assigned by the caller
             self._codebook_dev = torch.from_numpy(np.ascontiguousarray(self.codebook, dtype=np.float64)).to(
                 self._engine.device)
-        labels_dev = self._engine.encode(self._blocks_dev, self._codebook_dev)
+        labels_dev = self._engine.encode(self._blocks_dev, self._codebook_dev, sorted=self._sorted_blocks())
         self._labels_dev = labels_dev
         labels_grid = labels_dev.cpu().numpy().astype(np.int64).reshape(self.n_rows, self.n_cols)
 

@@ -61,15 +61,13 @@ int fail(int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(VQ_E_HIP, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
     } while (0)
 
-constexpr int ABI_VERSION = 1;
+constexpr int ABI_VERSION = 2;
 constexpr int WAVE = 64;
-constexpr int MAX_GRID = 4096;          // upper bound on workgroups of the assignment kernels
 constexpr int64_t NP_CHUNK = 8192;      // numpy's reduction buffer: elements per pairwise-summed chunk
 constexpr int MAX_D_FAST = 192;         // largest vector dimension of the SAD filter kernels
 constexpr int MAX_K = 1 << 20;
 
-// Tuning knobs of the d <= 16 filter kernels: vectors per lane, codewords per scalar-load batch,
-// resident 256-thread workgroups per CU the grid is sized for.
+// Tuning knobs of the d <= 16 filter kernels: vectors per lane, codewords per scalar-load batch.
 #ifndef VQ_R8
 #define VQ_R8 4
 #endif
@@ -79,22 +77,46 @@ constexpr int MAX_K = 1 << 20;
 #ifndef VQ_RBIG
 #define VQ_RBIG 2
 #endif
-#ifndef VQ_WG_PER_CU
-#define VQ_WG_PER_CU 8
+// Pruned search: vectors per lane, codewords added per side and round.
+#ifndef VQ_RP
+#define VQ_RP 4
 #endif
+#ifndef VQ_GP
+#define VQ_GP 16
+#endif
+
+// Sorted-codebook position table: entry t = number of codewords whose fixed-point element sum is
+// below t << tshift; POSTAB_NT + 2 entries are used at most.
+constexpr int POSTAB_NT = 1024;
+constexpr int POSTAB_WORDS = POSTAB_NT + 8;
+constexpr int PREP_SORT_CAP = 2048;     // codebooks up to this size are sorted by element sum
+constexpr int SORT_WIN = 8192;          // vectors per window of the windowed vector sort
+constexpr int SORT_BUCKETS = 2048;      // counting-sort buckets per window
+
+// Ambiguous vectors are queued in NQ sub-queues, each with its own counter in its own cache line:
+// the group of 64 consecutive vectors g goes to sub-queue g % NQ.  (One counter for the whole
+// launch serialises some 10^4 same-address atomics and was measured to bound the kernel.)
+constexpr int NQ = 64;
+inline size_t queue_cap(int64_t N) {                       // entries per sub-queue
+    const size_t groups = ((size_t)N + 63) / 64;
+    return (groups + NQ - 1) / NQ * 64;
+}
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Workspace layout (all offsets multiples of 256 bytes).
 struct WsLayout {
     size_t header;     // PrepHeader
-    size_t c16;        // K * dp2 uint32: codebook as packed pairs of 16-bit fixed point
-    size_t bias;       // K uint32: key bias (index, plus the never-wins bit for duplicate rows)
+    size_t c16;        // Kpad * dp2 uint32: codebook as packed pairs of 16-bit fixed point, rows in
+                       // ascending order of their element sum (Kpad = K rounded up to 8; pad rows never win)
+    size_t bias;       // Kpad uint32: key bias (original row index, plus the never-wins bit for duplicate rows)
+    size_t c16u;       // K * dp2 uint32: the same rows in original order (scratch of the prepare kernel)
+    size_t postab;     // POSTAB_WORDS uint32: sum threshold -> position in the sorted codebook
     size_t cbT;        // d * K doubles: transposed fp64 codebook
     size_t cb_u8;      // K * d bytes: codebook truncated to uint8 (decode)
     size_t chunks;     // ceil(N / 8192) + 1 doubles: per-chunk sums of the distance array
-    size_t qcount;     // one 256-byte slot: number of queued (ambiguous) vectors
-    size_t queue;      // N uint32: indices of the vectors the fix-up kernel must re-check
+    size_t qcount;     // NQ counters, 64 bytes apart: entries in each sub-queue of ambiguous vectors
+    size_t queue;      // NQ * queue_cap(N) uint32: indices of the vectors the fix-up kernel must re-check
     size_t total;
 };
 
@@ -106,13 +128,16 @@ WsLayout ws_layout(int K, int d, int64_t N) {
     if (dp2 <= 0) dp2 = (d + 1) / 2;
     size_t off = 0;
     L.header = off;   off += 256;
-    L.c16 = off;      off += align_up((size_t)K * dp2 * 4, 256);
-    L.bias = off;     off += align_up((size_t)K * 4, 256);
+    const size_t kpad = ((size_t)K + 7) / 8 * 8;
+    L.c16 = off;      off += align_up(kpad * dp2 * 4, 256);
+    L.bias = off;     off += align_up(kpad * 4, 256);
+    L.c16u = off;     off += align_up((size_t)K * dp2 * 4, 256);
+    L.postab = off;   off += align_up((size_t)POSTAB_WORDS * 4, 256);
     L.cbT = off;      off += align_up((size_t)K * d * 8, 256);
     L.cb_u8 = off;    off += align_up((size_t)K * d, 256);
     L.chunks = off;   off += align_up((size_t)((N + NP_CHUNK - 1) / NP_CHUNK + 1) * 8, 256);
-    L.qcount = off;   off += 256;
-    L.queue = off;    off += align_up((size_t)N * 4, 256);
+    L.qcount = off;   off += (size_t)NQ * 64;
+    L.queue = off;    off += align_up((size_t)NQ * queue_cap(N) * 4, 256);
     L.total = off;
     return L;
 }
@@ -122,7 +147,10 @@ struct PrepHeader {
     uint32_t shift;     // s: fixed-point scale is 2^s
     uint32_t emax;      // integer bound, strictly greater than every E_k (units of 2^-s)
     uint32_t cmax;      // ceil of the largest codebook entry, saturated
-    uint32_t pad[61];
+    uint32_t sorted;    // 1: rows of c16 / bias are in ascending order of element sum and postab is valid
+    uint32_t tshift;    // postab granularity: entry t covers sums [t << tshift, (t + 1) << tshift)
+    uint32_t nt;        // postab entries 0 .. nt + 1 are valid; entry nt + 1 = K
+    uint32_t pad[58];
 };
 static_assert(sizeof(PrepHeader) == 256, "header is one 256-byte slot");
 
@@ -133,6 +161,22 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
+}
+
+// Maximum / minimum of a 32-bit value over the 64 lanes of a (fully active) wave, returned as a
+// wave-uniform value.  Four DPP steps reduce each row of 16 lanes, scalar code joins the rows.
+template <bool IS_MAX>
+__device__ __forceinline__ uint32_t wave_reduce_u32(uint32_t v) {
+    auto op = [](uint32_t a, uint32_t b) { return IS_MAX ? (a > b ? a : b) : (a < b ? a : b); };
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false));   // row_half_mirror
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false));   // row_mirror
+    const uint32_t r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    const uint32_t r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    // readfirstlane marks the result as wave-uniform for the compiler: what is computed from it stays in
+    // scalar registers and table lookups indexed by it become scalar loads
+    return __builtin_amdgcn_readfirstlane(op(op(r0, r1), op(r2, r3)));
 }
 
 // fp64 -> uint8 the way numpy converts inside np.array(..., dtype=np.uint8): truncate toward
@@ -347,10 +391,15 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long h, unsign
 // then per slot the smallest row index seen for its key.
 __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb, int K, int d, int dp2, uint32_t clim,
                                                   PrepHeader *__restrict__ hdr, uint32_t *__restrict__ c16,
-                                                  uint32_t *__restrict__ bias, double *__restrict__ cbT) {
+                                                  uint32_t *__restrict__ bias, double *__restrict__ cbT,
+                                                  uint32_t *__restrict__ c16u, uint32_t *__restrict__ postab) {
     extern __shared__ __align__(16) unsigned long long s_keys[];
     __shared__ uint32_t s_cmax;
     __shared__ uint32_t s_emax;
+    __shared__ uint32_t s_sc[PREP_SORT_CAP];        // element sum of each fixed-point row, original order
+    __shared__ uint32_t s_scs[PREP_SORT_CAP];       // the same sums in ascending order
+    const bool do_sort = K <= PREP_SORT_CAP;
+    uint32_t *crow_out = do_sort ? c16u : c16;       // unsorted rows go to scratch first when sorting
     const bool scan_dups = K <= PREP_HASH_CAP && K > 1;
     const uint32_t T = scan_dups ? 2u * (uint32_t)K : 0u;       // table slots
     unsigned long long *s_rowhash = s_keys + T;                  // K entries
@@ -390,6 +439,7 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
         const double *row = cb + (size_t)k * d;
         double err = 0.0;
+        uint32_t sc = 0;
         unsigned long long h = 0x243F6A8885A308D3ull;
         for (int p0 = 0; p0 < dp2; p0 += 4) {
             double c[8];
@@ -416,14 +466,16 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
                             if (!(de == de)) de = 4.0e9;
                             err += de;
                             pair |= ((uint32_t)q) << (16 * hh);
+                            sc += (uint32_t)q;
                             cbT[(size_t)e * K + k] = cv;
                             h = mix64(h, (unsigned long long)__double_as_longlong(cv));
                         }
                     }
-                    c16[(size_t)k * dp2 + p] = pair;
+                    crow_out[(size_t)k * dp2 + p] = pair;
                 }
             }
         }
+        if (do_sort) s_sc[k] = sc;
         // strict integer upper bound of err (plus slack for the fp64 rounding of err itself)
         uint32_t ek = (err < 2.0e9) ? (uint32_t)err + 2u : 0x7fffffffu;
         atomicMax(&s_emax, ek);
@@ -470,12 +522,128 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
                 dup = e == d ? 1u : 0u;
             }
         }
-        bias[k] = (uint32_t)k | (dup << 31);
+        // phase D: position of the row in ascending (element sum, index) order, by counting
+        uint32_t pos = (uint32_t)k;
+        if (do_sort) {
+            const uint32_t me = s_sc[k];
+            pos = 0;
+            for (int j = 0; j < K; ++j) {
+                const uint32_t o = s_sc[j];
+                pos += (o < me || (o == me && j < k)) ? 1u : 0u;
+            }
+            s_scs[pos] = me;
+            for (int p = 0; p < dp2; ++p) c16[(size_t)pos * dp2 + p] = c16u[(size_t)k * dp2 + p];
+        }
+        bias[pos] = (uint32_t)k | (dup << 31);
+    }
+    // pad rows: zeros with the never-competes bias, so that batches of codewords may run past K
+    const int kpad = (K + 7) / 8 * 8;
+    for (int i = threadIdx.x; i < (kpad - K) * dp2; i += blockDim.x) c16[(size_t)K * dp2 + i] = 0u;
+    for (int i = K + threadIdx.x; i < kpad; i += blockDim.x) bias[i] = 0x80000000u;
+    // position table over the sums a vector can have: 0 .. d * 255 << s
+    const uint32_t mtab = (uint32_t)d * (255u << s) + 1u;
+    uint32_t tshift = 0;
+    while ((mtab >> tshift) > (uint32_t)POSTAB_NT - 1u) ++tshift;
+    const uint32_t nt = (mtab >> tshift) + 1u;                 // entries 0 .. nt cover every vector sum
+    if (do_sort) {
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t <= nt + 1u; t += blockDim.x) {
+            uint32_t lo = 0, hi = (uint32_t)K;                 // lower bound of (t << tshift) in s_scs
+            const uint64_t target = (uint64_t)t << tshift;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if ((uint64_t)s_scs[mid] < target) lo = mid + 1; else hi = mid;
+            }
+            postab[t] = t == nt + 1u ? (uint32_t)K : lo;
+        }
     }
     if (threadIdx.x == 0) {
         hdr->shift = (uint32_t)s;
         hdr->emax = s_emax;
         hdr->cmax = cmax;
+        hdr->sorted = do_sort ? 1u : 0u;
+        hdr->tshift = tshift;
+        hdr->nt = nt;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// windowed sort of the block vectors by element sum (input of the pruned search)
+// ------------------------------------------------------------------------------------------------
+// One workgroup per window of SORT_WIN vectors: a counting sort on the element sum (bucketed) places
+// every vector of the window at its sorted position in `rows` and records where it came from in
+// `perm` (position inside the window).  Vectors never leave their window, so everything the search
+// later writes per vector (label, distance) lands within 32 / 64 KB of its neighbours.  The order
+// inside a bucket depends on the order the atomics retire in; nothing computed from the sorted copy
+// depends on it.  VEC16: d == 16 and 16-byte aligned rows (one 16-byte load and store per vector).
+template <bool VEC16>
+__global__ __launch_bounds__(1024) void k_window_sort(const uint8_t *__restrict__ blocks, int64_t N, int d, int bshift,
+                                                      uint8_t *__restrict__ rows, uint16_t *__restrict__ perm) {
+    constexpr int T = 1024;
+    constexpr int PER = SORT_WIN / T;                       // vectors per thread
+    __shared__ uint32_t s_cnt[SORT_BUCKETS];
+    __shared__ uint32_t s_wsum[T / WAVE];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
+    const int64_t w0 = (int64_t)blockIdx.x * SORT_WIN;
+    for (int i = tid; i < SORT_BUCKETS; i += T) s_cnt[i] = 0u;
+    __syncthreads();
+    uint4 keep[PER];
+    uint32_t bucket[PER], rank[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int64_t n = w0 + (int64_t)j * T + tid;
+        bucket[j] = 0xffffffffu;
+        rank[j] = 0;
+        if (n < N) {
+            uint32_t sum = 0;
+            if (VEC16) {
+                const uint4 v = reinterpret_cast<const uint4 *>(blocks)[n];
+                keep[j] = v;
+                sum = __builtin_amdgcn_sad_u8(v.x, 0u, sum);
+                sum = __builtin_amdgcn_sad_u8(v.y, 0u, sum);
+                sum = __builtin_amdgcn_sad_u8(v.z, 0u, sum);
+                sum = __builtin_amdgcn_sad_u8(v.w, 0u, sum);
+            } else {
+                const uint8_t *row = blocks + (size_t)n * d;
+                for (int e = 0; e < d; ++e) sum += row[e];
+            }
+            bucket[j] = sum >> bshift;
+            rank[j] = atomicAdd(&s_cnt[bucket[j]], 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the bucket counts: two buckets per thread, wave scan, then the wave totals
+    const uint32_t c0 = s_cnt[2 * tid], c1 = s_cnt[2 * tid + 1];
+    uint32_t incl = c0 + c1;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, WAVE);
+        if (lane >= off) incl += o;
+    }
+    if (lane == WAVE - 1) s_wsum[wv] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int i = 0; i < wv; ++i) wbase += s_wsum[i];
+    const uint32_t excl = wbase + incl - (c0 + c1);
+    __syncthreads();
+    s_cnt[2 * tid] = excl;
+    s_cnt[2 * tid + 1] = excl + c0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int li = j * T + tid;
+        const int64_t n = w0 + li;
+        if (n < N) {
+            const int64_t slot = w0 + (int64_t)(s_cnt[bucket[j]] + rank[j]);
+            if (VEC16) {
+                reinterpret_cast<uint4 *>(rows)[slot] = keep[j];
+            } else {
+                const uint8_t *src = blocks + (size_t)n * d;
+                uint8_t *dst = rows + (size_t)slot * d;
+                for (int e = 0; e < d; ++e) dst[e] = src[e];
+            }
+            perm[slot] = (uint16_t)li;
+        }
     }
 }
 
@@ -483,10 +651,6 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
 // nearest codeword, FAST mode (VQ_Full.py:77-78 / :124-125), optionally fused with the
 // per-cluster accumulation of VQ_Full.py:81-90
 // ------------------------------------------------------------------------------------------------
-constexpr int ACC_NONE = 0;     // labels (+ distances) only
-constexpr int ACC_LDS = 1;      // cluster sums / counts through an LDS table, flushed with 64-bit atomics
-                                // (tables beyond the LDS are served by k_accum_rows after the search)
-
 constexpr int KEY_PACKED = 0;   // key = (S << kbits) + (k | dupbit): needs S << kbits < 2^31
 constexpr int KEY_SPLIT = 1;    // value and index tracked separately
 
@@ -500,14 +664,16 @@ struct AssignArgs {
     const PrepHeader *hdr;
     int32_t *labels;            // N; written for unambiguous vectors only
     double *min_dist;           // nullable; written for unambiguous vectors only
-    uint32_t *queue;            // indices of ambiguous vectors, appended in no particular order
-    uint32_t *qcount;           // number of queue entries (zeroed before the launch)
-    unsigned long long *sums;   // ACC_*: (K, d)
-    unsigned long long *counts; // ACC_*: (K)
-    int acc_mode;
-    int tab_words;              // words of dynamic LDS in front of the codeword tiles (the ACC_LDS table, padded)
-    int vec4;                   // rows may be read as aligned 32-bit words (d % 4 == 0, base 4-byte aligned)
+    uint32_t *queue;            // NQ sub-queues of qcap entries: indices of ambiguous vectors, in no particular order
+    uint32_t *qcount;           // entries per sub-queue, counter q at qcount[16 * q] (zeroed before the launch)
+    uint32_t qcap;
+    int vec4;                   // 1: rows may be read as aligned 32-bit words (d % 4 == 0, base 4-byte aligned);
+                                // 2: rows are exactly 16 bytes and 16-byte aligned
     int64_t ntiles;
+    // PRUNE: the search reads the window-sorted copy of the vectors and skips codewords by element sum
+    const uint8_t *rows;        // N * d bytes: the vectors, each window of SORT_WIN sorted by element sum
+    const uint16_t *perm;       // N: position inside its window of the vector now at sorted position i
+    const uint32_t *postab;     // sum threshold -> position in the sorted codebook
 };
 
 // Codewords per LDS tile of the LDS_CW variant (about 4 KB of fixed-point rows per tile).
@@ -518,24 +684,32 @@ constexpr int tile_k_for(int dp2) { return dp2 <= 8 ? 128 : (dp2 <= 16 ? 64 : (d
 // double-buffered tiles (wide vector loads, one barrier per tile) and every wave reads the rows
 // back as broadcast LDS reads; this serves large dimensions (a row no longer fits the scalar
 // registers) and codebooks far beyond the scalar cache.
-template <int DP2, int R, int KEYMODE, bool LDS_CW>
-__global__ __launch_bounds__(512) void k_assign_fast(const AssignArgs a, const uint32_t *__restrict__ c16,
+//
+// PRUNE (scalar-load variant only): the vectors are read from a copy in which every window of
+// SORT_WIN vectors is sorted by element sum, so the 64 * R vectors of a wave have nearly the same
+// sum, and the fixed-point codebook rows are in ascending order of THEIR element sum.  Since
+// sum_e |X_e - C_e| >= |sum_e X_e - sum_e C_e| holds exactly in integers, a codeword whose sum lies
+// further from every vector sum of the wave than the wave's worst current best distance plus the
+// ambiguity window can be neither the nearest nor a near-tie for any of them: the wave searches a
+// contiguous range of the sorted codebook around its own sum, widening it in steps and narrowing
+// the bound as the best distances improve.  Results are identical to the full search.
+#ifdef VQ_WAVES_PER_EU
+#define VQ_ASSIGN_ATTR __attribute__((amdgpu_waves_per_eu(VQ_WAVES_PER_EU, VQ_WAVES_PER_EU)))
+#else
+#define VQ_ASSIGN_ATTR
+#endif
+template <int DP2, int R, int KEYMODE, bool LDS_CW, bool PRUNE>
+__global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const AssignArgs a, const uint32_t *__restrict__ c16,
                                                      const uint32_t *__restrict__ bias) {
-    // dynamic LDS: [ACC_LDS table: K * (d + 1) words, [sums | count] per codeword, padded to 16 B]
-    //              [LDS_CW: 2 tiles of TILE_K * DP2 words][2 x TILE_K bias words]
+    static_assert(!(PRUNE && LDS_CW), "pruning is built for the scalar-load variant");
+    // dynamic LDS (LDS_CW only): [2 tiles of TILE_K * DP2 words][2 x TILE_K bias words]
     extern __shared__ __align__(16) uint32_t s_tab[];
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int BLOCK = blockDim.x;
     const int d = a.d, K = a.K;
-    const int acc_mode = a.acc_mode;
-    const int tabn = K * (d + 1);
     const bool want_dist = a.min_dist != nullptr;
 
-    if (acc_mode == ACC_LDS) {
-        for (int i = tid; i < tabn; i += BLOCK) s_tab[i] = 0u;
-        __syncthreads();
-    }
     const uint32_t s = a.hdr->shift;
     const uint32_t emax = a.hdr->emax;
     const uint32_t window = emax >= 0x3fffffffu ? 0xffffffffu : 2u * emax;   // ambiguous iff S2 - S1 <= window
@@ -545,20 +719,41 @@ __global__ __launch_bounds__(512) void k_assign_fast(const AssignArgs a, const u
     // bias as its single scalar operand (one instruction instead of shift + add).
     uint32_t kbits_v = kbits;
     asm volatile("" : "+v"(kbits_v));
-    int tiles_done = 0;
 
-    for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    // Workgroups are handed to the 8 XCDs round-robin.  When pruning, the tiles of one sort window write
+    // their labels and distances into the same 32 / 64 KB of output, so consecutive tiles are given to
+    // workgroups of the same XCD (one L2 then sees all writes to a line before it is evicted).
+    int64_t first_tile = blockIdx.x;
+    if (PRUNE && (gridDim.x & 7) == 0) first_tile = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    for (int64_t tile = first_tile; tile < a.ntiles; tile += gridDim.x) {
         const int64_t base = tile * (int64_t)(BLOCK * R);
         // ---- load R vectors per lane and convert to packed 16-bit fixed point ----
         uint32_t x[R][DP2];
+        uint32_t origin[R];                                    // PRUNE: where in its window the vector came from
+        // position of lane's r-th vector: a wave takes 64 * R consecutive vectors when pruning (they are
+        // neighbours in sorted order), otherwise the R vectors of a lane are a workgroup apart
+        auto vec_index = [&](int r) -> int64_t {
+            return PRUNE ? base + (int64_t)(tid >> 6) * (WAVE * R) + r * WAVE + lane : base + (int64_t)r * BLOCK + tid;
+        };
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            int64_t n = base + (int64_t)r * BLOCK + tid;
+            int64_t n = vec_index(r);
             if (n >= a.N) n = a.N - 1;                 // clamp: loads stay in bounds, result is discarded
-            const uint8_t *row = a.blocks + (size_t)n * d;
+            const uint8_t *row = (PRUNE ? a.rows : a.blocks) + (size_t)n * d;
+            origin[r] = PRUNE ? (uint32_t)a.perm[n] : 0u;
             // Out-of-row positions (d below the template's padded size) are loaded from a clamped
             // index and then zeroed, so that no load sits behind a branch.
-            if (a.vec4) {
+            if (DP2 == 8 && a.vec4 == 2) {
+                // 16-byte rows, 16-byte aligned: one load per vector
+                const uint4 v = *reinterpret_cast<const uint4 *>(row);
+                const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int wi = 0; wi < 4; ++wi) {
+                    const uint32_t w = w4[wi];
+                    x[r][2 * wi] = ((w & 0xffu) | ((w & 0xff00u) << 8)) << s;
+                    x[r][2 * wi + 1] = (((w >> 16) & 0xffu) | ((w >> 8) & 0xff0000u)) << s;
+                }
+            } else if (a.vec4) {
                 const uint32_t *row4 = reinterpret_cast<const uint32_t *>(row);
                 const int nw = d >> 2;
 #pragma unroll
@@ -619,30 +814,75 @@ __global__ __launch_bounds__(512) void k_assign_fast(const AssignArgs a, const u
             // Codewords are fetched by scalar loads (wave-uniform addresses) in batches of U, so that
             // one scalar-memory wait is paid per U * R * (DP2 + 3) vector instructions.
             constexpr int U = DP2 <= 8 ? VQ_U8 : (DP2 <= 16 ? 2 : 1);
-            int k = 0;
-            for (; k + U <= K; k += U) {
-                uint32_t cw[U][DP2], b[U];
+            // rows [lo, hi) of the fixed-point codebook, hi - lo a multiple of U (rows K .. Kpad are
+            // pad rows that never win)
+            auto run = [&](int lo, int hi) {
+                for (int k = lo; k < hi; k += U) {
+                    uint32_t cw[U][DP2], b[U];
 #pragma unroll
-                for (int j = 0; j < U; ++j) {
+                    for (int j = 0; j < U; ++j) {
 #pragma unroll
-                    for (int p = 0; p < DP2; ++p) cw[j][p] = c16[(size_t)(k + j) * DP2 + p];
-                    b[j] = bias[k + j];
+                        for (int p = 0; p < DP2; ++p) cw[j][p] = c16[(size_t)(k + j) * DP2 + p];
+                        b[j] = bias[k + j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < U; ++j) step(cw[j], b[j], k + j);
                 }
+            };
+            const int kpad = (K + 7) & ~7;
+            if constexpr (!PRUNE) {
+                run(0, (K + U - 1) / U * U);
+            } else {
+                // wave-uniform range of the vectors' element sums (same fixed-point units as the rows)
+                uint32_t sxlo = 0xffffffffu, sxhi = 0u;
 #pragma unroll
-                for (int j = 0; j < U; ++j) step(cw[j], b[j], k + j);
-            }
-            for (; k < K; ++k) {
-                uint32_t cw[DP2];
+                for (int r = 0; r < R; ++r) {
+                    uint32_t sx = 0;
 #pragma unroll
-                for (int p = 0; p < DP2; ++p) cw[p] = c16[(size_t)k * DP2 + p];
-                step(cw, bias[k], k);
+                    for (int p = 0; p < DP2; ++p) sx = __builtin_amdgcn_sad_u16(x[r][p], 0u, sx);
+                    sxlo = min(sxlo, sx);
+                    sxhi = max(sxhi, sx);
+                }
+                sxlo = wave_reduce_u32<false>(sxlo);
+                sxhi = wave_reduce_u32<true>(sxhi);
+                const uint32_t tshift = a.hdr->tshift, nt = a.hdr->nt;
+                constexpr int G = VQ_GP;                       // codewords added per side and round
+                int pa = (int)(a.postab[((sxlo >> 1) + (sxhi >> 1)) >> tshift] & ~7u) - G / 2;
+                if (pa > kpad - G) pa = kpad - G;
+                if (pa < 0) pa = 0;
+                int pb = pa + G < kpad ? pa + G : kpad;
+                // segments still to search this round: [l0, h0) and [l1, h1); [pa, pb) is what has been searched
+                int l0 = pa, h0 = pb, l1 = 0, h1 = 0;
+                for (;;) {
+#pragma nounroll
+                    for (int sg = 0; sg < 2; ++sg) run(sg ? l1 : l0, sg ? h1 : h0);
+                    uint32_t bm = 0;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) bm = max(bm, m1[r]);
+                    bm = wave_reduce_u32<true>(bm);
+                    if (KEYMODE == KEY_PACKED) bm >>= kbits;   // worst "best SAD so far" of the wave
+                    uint32_t thr = bm + window;                // a codeword further away than this matters to no vector
+                    if (thr < bm) thr = 0xffffffffu;
+                    const uint32_t lo_sum = sxlo > thr ? sxlo - thr : 0u;
+                    const unsigned long long hi_sum = (unsigned long long)sxhi + thr;
+                    unsigned long long ih = (hi_sum >> tshift) + 1ull;
+                    if (ih > nt + 1ull) ih = nt + 1ull;
+                    const int klo = (int)(a.postab[lo_sum >> tshift] & ~7u);
+                    const int khi = (int)((a.postab[ih] + 7u) & ~7u);
+                    const int na = pa > klo ? (pa - G > klo ? pa - G : klo) : pa;
+                    const int nb = pb < khi ? (pb + G < khi ? pb + G : khi) : pb;
+                    if (na == pa && nb == pb) break;
+                    l0 = na; h0 = pa; l1 = pb; h1 = nb;
+                    pa = na;
+                    pb = nb;
+                }
             }
         } else {
             constexpr int TILE_K = tile_k_for(DP2);
             constexpr int TILE_W = TILE_K * DP2;               // words of fixed-point rows per tile
             constexpr int NV = TILE_W / 4;                     // 16-byte pieces per tile
             constexpr int MAXL = (NV + 255) / 256;             // pieces per thread (workgroups have >= 256 threads)
-            uint32_t *s_cw = s_tab + a.tab_words;
+            uint32_t *s_cw = s_tab;
             uint32_t *s_b = s_cw + 2 * TILE_W;
             const int ntk = (K + TILE_K - 1) / TILE_K;
             const uint32_t total_w = (uint32_t)K * DP2;
@@ -733,8 +973,11 @@ __global__ __launch_bounds__(512) void k_assign_fast(const AssignArgs a, const u
         // ---- decide, measure, write, accumulate ----
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const int64_t n = base + (int64_t)r * BLOCK + tid;
-            const bool valid = n < a.N;
+            const int64_t ns = vec_index(r);                   // position in the order the vectors were read in
+            const bool valid = ns < a.N;
+            // index of the vector in the caller's order: the sorted copy keeps every vector inside its window
+            int64_t n = ns;
+            if (PRUNE) n = (ns & ~(int64_t)(SORT_WIN - 1)) + (int64_t)origin[r];
             uint32_t s1, s2;
             int idx;
             if (KEYMODE == KEY_PACKED) {
@@ -742,7 +985,7 @@ __global__ __launch_bounds__(512) void k_assign_fast(const AssignArgs a, const u
                 s1 = m1[r] >> kbits;
                 s2 = m2[r] >> kbits;
             } else {
-                idx = (int)bi[r];
+                idx = (int)(bias[bi[r]] & 0x7fffffffu);         // rows are stored sorted: position -> codeword index
                 s1 = m1[r];
                 s2 = m2[r];
             }
@@ -752,10 +995,12 @@ __global__ __launch_bounds__(512) void k_assign_fast(const AssignArgs a, const u
             const unsigned long long amask = __ballot(amb);
             if (amask) {
                 const int leader = __ffsll((long long)amask) - 1;
+                const uint32_t q = (uint32_t)((ns - lane) >> 6) & (NQ - 1);    // sub-queue of this group of 64 vectors
                 uint32_t qbase = 0;
-                if (lane == leader) qbase = atomicAdd(a.qcount, (uint32_t)__popcll(amask));
+                if (lane == leader) qbase = atomicAdd(a.qcount + 16 * q, (uint32_t)__popcll(amask));
                 qbase = __builtin_amdgcn_readlane(qbase, leader);
-                if (amb) a.queue[qbase + (uint32_t)__popcll(amask & ((1ull << lane) - 1ull))] = (uint32_t)n;
+                if (amb)
+                    a.queue[(size_t)q * a.qcap + qbase + (uint32_t)__popcll(amask & ((1ull << lane) - 1ull))] = (uint32_t)n;
             }
             if (!valid || amb) continue;
             a.labels[n] = idx;
@@ -775,51 +1020,12 @@ __global__ __launch_bounds__(512) void k_assign_fast(const AssignArgs a, const u
                 }
                 a.min_dist[n] = acc;
             }
-            if (acc_mode == ACC_LDS) {
-                uint32_t *t = s_tab + (size_t)idx * (d + 1);
-#pragma unroll
-                for (int p = 0; p < DP2; ++p) {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        int e = 2 * p + h;
-                        if (e < d) atomicAdd(&t[e], (x[r][p] >> (s + 16 * h)) & 0xffu);
-                    }
-                }
-                atomicAdd(&t[d], 1u);
-            }
-        }
-        // 32-bit LDS sums hold 255 * (vectors per workgroup): flush long before they can wrap
-        if (acc_mode == ACC_LDS && (++tiles_done & 1023) == 0) {
-            __syncthreads();
-            for (int i = tid; i < tabn; i += BLOCK) {
-                uint32_t v = s_tab[i];
-                if (v) {
-                    int kk = i / (d + 1), e = i - kk * (d + 1);
-                    if (e < d) atomicAdd(&a.sums[(size_t)kk * d + e], (unsigned long long)v);
-                    else atomicAdd(&a.counts[kk], (unsigned long long)v);
-                    s_tab[i] = 0u;
-                }
-            }
-            __syncthreads();
-        }
-    }
-
-    if (acc_mode == ACC_LDS) {
-        __syncthreads();
-        for (int i = tid; i < tabn; i += BLOCK) {
-            uint32_t v = s_tab[i];
-            if (v) {
-                int kk = i / (d + 1), e = i - kk * (d + 1);
-                if (e < d) atomicAdd(&a.sums[(size_t)kk * d + e], (unsigned long long)v);
-                else atomicAdd(&a.counts[kk], (unsigned long long)v);
-            }
         }
     }
 }
 
 // Fix-up pass of FAST mode: every queued vector is searched again by a whole wave in sequential
-// fp64 (exact_search_wave); its label, its distance and -- when sums is non-null -- its
-// contribution to the cluster sums are written here.  Waves stride over the queue, so the work is
+// fp64 (exact_search_wave); its label and its distance are written here.  Waves stride over the queue, so the work is
 // balanced however the ambiguous vectors cluster in the image; results do not depend on queue order.
 // A wave fetches the queue entries and vector rows of four items at once (two memory round trips
 // per four items); with LDS_CB the transposed codebook is staged in LDS once per workgroup.
@@ -827,22 +1033,32 @@ template <bool LDS_CB>
 __global__ __launch_bounds__(1024) void k_fixup(const uint8_t *__restrict__ blocks, int d,
                                                 const double *__restrict__ cbT, int K,
                                                 const uint32_t *__restrict__ queue,
-                                                const uint32_t *__restrict__ qcount, int32_t *__restrict__ labels,
-                                                double *__restrict__ min_dist, unsigned long long *__restrict__ sums,
-                                                unsigned long long *__restrict__ counts) {
+                                                const uint32_t *__restrict__ qcount, uint32_t qcap,
+                                                int32_t *__restrict__ labels, double *__restrict__ min_dist) {
     extern __shared__ __align__(16) double s_cbT[];
     const int lane = threadIdx.x & (WAVE - 1);
     const uint32_t waves_per_wg = blockDim.x >> 6;
     const uint32_t wave = blockIdx.x * waves_per_wg + (threadIdx.x >> 6);
-    const uint32_t nwaves = gridDim.x * waves_per_wg;
-    const uint32_t count = qcount[0];
-    if (blockIdx.x * waves_per_wg >= count) return;            // nothing for this workgroup (uniform)
+    // wave w serves sub-queue w % NQ, as the (w / NQ)-th of the nwaves / NQ waves that share it (the
+    // host launches a multiple of NQ waves)
+    const uint32_t nwaves = gridDim.x * waves_per_wg / NQ;
+    const uint32_t sub = wave & (NQ - 1);
+    const uint32_t rank = wave / NQ;
+    // nothing for this workgroup (uniform): none of its waves' sub-queues reaches their rank
+    bool any = false;
+    for (uint32_t w = 0; w < waves_per_wg; ++w) {
+        const uint32_t ww = blockIdx.x * waves_per_wg + w;
+        any = any || qcount[16 * (ww & (NQ - 1))] > ww / NQ;
+    }
+    if (!any) return;
     if (LDS_CB) {
         const int n = K * d;
         for (int i = threadIdx.x; i < n; i += blockDim.x) s_cbT[i] = cbT[i];
         __syncthreads();
     }
-    for (uint32_t i0 = wave; i0 < count; i0 += 4 * nwaves) {
+    const uint32_t count = qcount[16 * sub];
+    queue += (size_t)sub * qcap;
+    for (uint32_t i0 = rank; i0 < count; i0 += 4 * nwaves) {
         int64_t n[4];
         uint32_t xv[4];
 #pragma unroll
@@ -862,13 +1078,6 @@ __global__ __launch_bounds__(1024) void k_fixup(const uint8_t *__restrict__ bloc
             if (lane == 0) {
                 labels[n[t]] = ri;
                 if (min_dist) min_dist[n[t]] = rd;
-            }
-            if (sums) {
-                for (int e = lane; e < d; e += WAVE) {
-                    unsigned v = xrow[e];
-                    if (v) atomicAdd(&sums[(size_t)ri * d + e], (unsigned long long)v);
-                }
-                if (lane == 0) atomicAdd(&counts[ri], 1ull);
             }
         }
     }
@@ -1065,6 +1274,82 @@ __global__ __launch_bounds__(256) void k_accum_rows(const uint8_t *__restrict__ 
     }
 }
 
+// Per-cluster sums / counts for given labels through a per-workgroup LDS table [K][d+1] of 32-bit
+// words (ds_add_u32), flushed with 64-bit global atomics: integer, so the totals do not depend on
+// the order.  The vectors are taken in the caller's order, where neighbouring lanes mostly hold
+// different labels (few same-address LDS conflicts).  With min_dist non-null the kernel also
+// evaluates sum_e |x_e - cb[label][e]| in sequential fp64 (the value VQ_Full.py:89 gathers) for
+// every vector; CB_LDS stages the fp64 codebook in LDS behind the table.  VEC16: 16-byte rows.
+template <bool VEC16, bool CB_LDS>
+__global__ __launch_bounds__(256) void k_accum_dist(const uint8_t *__restrict__ blocks, int64_t N, int d,
+                                                    const int32_t *__restrict__ labels,
+                                                    const double *__restrict__ cb, int K,
+                                                    unsigned long long *__restrict__ sums,
+                                                    unsigned long long *__restrict__ counts,
+                                                    double *__restrict__ min_dist) {
+    extern __shared__ __align__(16) uint32_t s_acc[];
+    const int tid = threadIdx.x;
+    const int tabn = K * (d + 1);
+    const double *s_cb = reinterpret_cast<const double *>(s_acc + ((tabn + 3) & ~3));
+    for (int i = tid; i < tabn; i += blockDim.x) s_acc[i] = 0u;
+    if (CB_LDS) {
+        double *dst = reinterpret_cast<double *>(s_acc + ((tabn + 3) & ~3));
+        for (int i = tid; i < K * d; i += blockDim.x) dst[i] = cb[i];
+    }
+    __syncthreads();
+    auto flush = [&]() {
+        for (int i = tid; i < tabn; i += blockDim.x) {
+            const uint32_t v = s_acc[i];
+            if (v) {
+                const int kk = i / (d + 1), e = i - kk * (d + 1);
+                if (e < d) atomicAdd(&sums[(size_t)kk * d + e], (unsigned long long)v);
+                else atomicAdd(&counts[kk], (unsigned long long)v);
+                s_acc[i] = 0u;
+            }
+        }
+    };
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    uint32_t trips = 0;
+    for (int64_t n0 = (int64_t)blockIdx.x * blockDim.x; n0 < N; n0 += stride) {
+        const int64_t n = n0 + tid;
+        if (n < N) {
+            const int k = labels[n];
+            if ((unsigned)k < (unsigned)K) {
+                uint32_t *t = s_acc + (size_t)k * (d + 1);
+                const double *crow = CB_LDS ? s_cb + (size_t)k * d : cb + (size_t)k * d;
+                double acc = 0.0;
+                if (VEC16) {
+                    const uint4 v = reinterpret_cast<const uint4 *>(blocks)[n];
+                    const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const uint32_t b = (w4[e >> 2] >> (8 * (e & 3))) & 0xffu;
+                        atomicAdd(&t[e], b);
+                        if (min_dist) acc += fabs((double)b - crow[e]);
+                    }
+                } else {
+                    const uint8_t *x = blocks + (size_t)n * d;
+                    for (int e = 0; e < d; ++e) {
+                        const uint32_t b = x[e];
+                        atomicAdd(&t[e], b);
+                        if (min_dist) acc += fabs((double)b - crow[e]);
+                    }
+                }
+                atomicAdd(&t[d], 1u);
+                if (min_dist) min_dist[n] = acc;
+            }
+        }
+        // 32-bit LDS sums hold at most 255 * 256 per trip: flush long before they can wrap
+        if ((++trips & 0xffffu) == 0) {
+            __syncthreads();
+            flush();
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    flush();
+}
+
 // ------------------------------------------------------------------------------------------------
 // decode (VQ_Full.py:157-169)
 // ------------------------------------------------------------------------------------------------
@@ -1194,11 +1479,11 @@ int grid_for(int64_t work_items, int block, int max_blocks) {
 // Vectors per lane: the scalar-load variant serves d <= 32, the LDS variant everything.
 constexpr int r_lds_for(int dp2) { return dp2 <= 32 ? 4 : 2; }
 
-template <int DP2, int KEYMODE, bool LDS_CW>
+template <int DP2, int KEYMODE, bool LDS_CW, bool PRUNE = false>
 int launch_assign_fast_t(const AssignArgs &a, const uint32_t *c16, const uint32_t *bias, int block, int grid,
                          size_t lds, hipStream_t st) {
-    constexpr int R = LDS_CW ? r_lds_for(DP2) : r_for(DP2);
-    auto kern = k_assign_fast<DP2, R, KEYMODE, LDS_CW>;
+    constexpr int R = PRUNE ? VQ_RP : (LDS_CW ? r_lds_for(DP2) : r_for(DP2));
+    auto kern = k_assign_fast<DP2, R, KEYMODE, LDS_CW, PRUNE>;
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
@@ -1209,8 +1494,12 @@ int launch_assign_fast_t(const AssignArgs &a, const uint32_t *c16, const uint32_
 
 template <int DP2>
 int launch_assign_fast_k(const AssignArgs &a, const uint32_t *c16, const uint32_t *bias, bool packed, bool lds_cw,
-                         int block, int grid, size_t lds, hipStream_t st) {
+                         bool prune, int block, int grid, size_t lds, hipStream_t st) {
     if constexpr (DP2 <= 16) {
+        if (!lds_cw && prune) {
+            if (packed) return launch_assign_fast_t<DP2, KEY_PACKED, false, true>(a, c16, bias, block, grid, lds, st);
+            return launch_assign_fast_t<DP2, KEY_SPLIT, false, true>(a, c16, bias, block, grid, lds, st);
+        }
         if (!lds_cw) {
             if (packed) return launch_assign_fast_t<DP2, KEY_PACKED, false>(a, c16, bias, block, grid, lds, st);
             return launch_assign_fast_t<DP2, KEY_SPLIT, false>(a, c16, bias, block, grid, lds, st);
@@ -1292,15 +1581,38 @@ int run_prepare(const double *cb, int K, int d, void *ws, hipStream_t st) {
     hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1024), hash_lds, st, cb, K, d, dp2, key_layout(K, dp2).clim,
                        reinterpret_cast<PrepHeader *>(w + L.header),
                        reinterpret_cast<uint32_t *>(w + L.c16), reinterpret_cast<uint32_t *>(w + L.bias),
-                       reinterpret_cast<double *>(w + L.cbT));
+                       reinterpret_cast<double *>(w + L.cbT), reinterpret_cast<uint32_t *>(w + L.c16u),
+                       reinterpret_cast<uint32_t *>(w + L.postab));
     LAUNCH_CHECK("k_prepare");
     return VQ_OK;
 }
 
+// Layout of the buffer vq_blocks_sort fills: the sorted rows, then the window-local origins.
+struct SortedLayout {
+    size_t rows;       // N * d bytes
+    size_t perm;       // N uint16
+    size_t total;
+};
+
+SortedLayout sorted_layout(int d, int64_t N) {
+    SortedLayout L;
+    L.rows = 0;
+    L.perm = align_up((size_t)N * d, 256);
+    L.total = L.perm + align_up((size_t)N * 2, 256);
+    return L;
+}
+
+// The pruned search serves the shapes of the scalar-load kernels, from the codebook size on at
+// which skipping codewords can pay for the bookkeeping.
+bool prune_supported(int K, int d) {
+    const int dp2 = dp2_bucket(d);
+    return dp2 > 0 && K >= 32 && K <= PREP_SORT_CAP && !use_lds_codewords(K, dp2);
+}
+
 // FAST mode on a prepared workspace: the filter kernel, then the fp64 fix-up of the vectors it
-// marked.  sums == nullptr -> encode only.
-int run_fast(const uint8_t *blocks, int64_t N, int d, const double *cb, int K, int32_t *labels, double *min_dist,
-             unsigned long long *sums, unsigned long long *counts, void *ws, hipStream_t st) {
+// queued.  Writes labels and, when min_dist is non-null, the winning fp64 distances.
+int run_fast(const uint8_t *blocks, const void *sorted, int64_t N, int d, const double *cb, int K, int32_t *labels,
+             double *min_dist, void *ws, hipStream_t st) {
     const int dp2 = dp2_bucket(d);
     WsLayout L = ws_layout(K, d, 0);
     char *w = static_cast<char *>(ws);
@@ -1311,7 +1623,8 @@ int run_fast(const uint8_t *blocks, int64_t N, int d, const double *cb, int K, i
     WsLayout LN = ws_layout(K, d, N);
     uint32_t *qcount = reinterpret_cast<uint32_t *>(w + LN.qcount);
     uint32_t *queue = reinterpret_cast<uint32_t *>(w + LN.queue);
-    HIP_TRY(hipMemsetAsync(qcount, 0, 256, st));
+    HIP_TRY(hipMemsetAsync(qcount, 0, (size_t)NQ * 64, st));
+    const uint32_t qcap = (uint32_t)queue_cap(N);
 
     DeviceInfo di;
     int rc = device_info(di);
@@ -1319,85 +1632,111 @@ int run_fast(const uint8_t *blocks, int64_t N, int d, const double *cb, int K, i
 
     const int kbits = ceil_log2(K);
     const bool packed = key_layout(K, dp2).packed;
-
-    int acc_mode = ACC_NONE;
-    size_t lds = 0;
-    int block = 256;
-    bool rows_pass = false;      // accumulate in a separate coalesced pass (table too large for the LDS)
-    if (sums) {
-        size_t tab = (size_t)K * (d + 1) * 4;
-        if (tab <= 40 * 1024) { acc_mode = ACC_LDS; lds = tab; block = 256; }
-        else if (tab <= di.lds_per_block) { acc_mode = ACC_LDS; lds = tab; block = 512; }
-        else { rows_pass = true; }
-    }
-    unsigned long long *ksums = rows_pass ? nullptr : sums;       // what the search kernels accumulate into
-    unsigned long long *kcounts = rows_pass ? nullptr : counts;
     const bool lds_cw = use_lds_codewords(K, dp2);
-    const int R = lds_cw ? r_lds_for(dp2) : r_for(dp2);
-    const size_t tab_bytes = (lds + 15) / 16 * 16;
-    if (lds_cw) lds = tab_bytes + (size_t)2 * tile_k_for(dp2) * (dp2 + 1) * 4;
+    const bool prune = sorted != nullptr && prune_supported(K, d);
+    const int R = prune ? VQ_RP : (lds_cw ? r_lds_for(dp2) : r_for(dp2));
+    const int block = 256;
+    const size_t lds = lds_cw ? (size_t)2 * tile_k_for(dp2) * (dp2 + 1) * 4 : 0;
     const int64_t tile = (int64_t)block * R;
     const int64_t ntiles = (N + tile - 1) / tile;
-    // Encode only: one tile per workgroup, so the dispatcher balances the chip and the last,
-    // partly filled round of workgroups runs at full clock (measured faster than any persistent
-    // grid).  LBG mode: a persistent grid, because every workgroup ends with a flush of its LDS
-    // table and fewer workgroups mean fewer global atomics.
-    int64_t max_grid = (int64_t)1 << 30;
-    if (acc_mode == ACC_LDS) {
-        int wg_per_cu = block == 256 ? VQ_WG_PER_CU : 4;
-        if (lds > 0) {
-            int by_lds = (int)((160 * 1024) / lds);
-            if (by_lds < 1) by_lds = 1;
-            if (by_lds < wg_per_cu) wg_per_cu = by_lds;
-        }
-        max_grid = (int64_t)di.cus * wg_per_cu;
-        if (max_grid > MAX_GRID) max_grid = MAX_GRID;
-    }
-    int grid = (int)(ntiles < max_grid ? ntiles : max_grid);
+    // One tile per workgroup: the dispatcher balances the chip and the last, partly filled round of
+    // workgroups runs at full clock (measured faster than any persistent grid).
+    int grid = (int)(ntiles < ((int64_t)1 << 30) ? ntiles : ((int64_t)1 << 30));
+    if (prune && grid >= 8) grid = (grid + 7) & ~7;               // a multiple of the XCD count (see the kernel's tile order)
     if (grid < 1) grid = 1;
 
     AssignArgs a;
     a.blocks = blocks; a.N = N; a.d = d; a.cb = cb; a.K = K; a.kbits = kbits; a.hdr = hdr;
-    a.labels = labels; a.min_dist = min_dist; a.sums = ksums; a.counts = kcounts;
-    a.queue = queue; a.qcount = qcount;
-    a.acc_mode = acc_mode; a.ntiles = ntiles; a.tab_words = (int)(tab_bytes / 4);
+    a.labels = labels; a.min_dist = min_dist;
+    a.queue = queue; a.qcount = qcount; a.qcap = qcap;
+    a.ntiles = ntiles;
     a.vec4 = ((d & 3) == 0) && ((reinterpret_cast<uintptr_t>(blocks) & 3) == 0);
+    if (d == 16 && (reinterpret_cast<uintptr_t>(blocks) & 15) == 0) a.vec4 = 2;     // whole 16-byte rows
+    a.rows = nullptr; a.perm = nullptr;
+    a.postab = reinterpret_cast<const uint32_t *>(w + L.postab);
+    if (prune) {
+        SortedLayout SL = sorted_layout(d, N);
+        const char *sp = static_cast<const char *>(sorted);
+        a.rows = reinterpret_cast<const uint8_t *>(sp + SL.rows);
+        a.perm = reinterpret_cast<const uint16_t *>(sp + SL.perm);
+        a.vec4 = ((d & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.rows) & 3) == 0);
+        if (d == 16 && (reinterpret_cast<uintptr_t>(a.rows) & 15) == 0) a.vec4 = 2;
+        if (SORT_WIN % tile != 0) return fail(VQ_E_HIP, "internal: sort window %d is not a multiple of the tile %lld", SORT_WIN, (long long)tile);
+    }
 
     switch (dp2) {
-        case 2:  rc = launch_assign_fast_k<2>(a, c16, bias, packed, lds_cw, block, grid, lds, st); break;
-        case 4:  rc = launch_assign_fast_k<4>(a, c16, bias, packed, lds_cw, block, grid, lds, st); break;
-        case 6:  rc = launch_assign_fast_k<6>(a, c16, bias, packed, lds_cw, block, grid, lds, st); break;
-        case 8:  rc = launch_assign_fast_k<8>(a, c16, bias, packed, lds_cw, block, grid, lds, st); break;
-        case 12: rc = launch_assign_fast_k<12>(a, c16, bias, packed, lds_cw, block, grid, lds, st); break;
-        case 16: rc = launch_assign_fast_k<16>(a, c16, bias, packed, lds_cw, block, grid, lds, st); break;
-        case 24: rc = launch_assign_fast_k<24>(a, c16, bias, packed, lds_cw, block, grid, lds, st); break;
-        case 32: rc = launch_assign_fast_k<32>(a, c16, bias, packed, lds_cw, block, grid, lds, st); break;
-        case 48: rc = launch_assign_fast_k<48>(a, c16, bias, packed, lds_cw, block, grid, lds, st); break;
-        case 64: rc = launch_assign_fast_k<64>(a, c16, bias, packed, lds_cw, block, grid, lds, st); break;
-        case 96: rc = launch_assign_fast_k<96>(a, c16, bias, packed, lds_cw, block, grid, lds, st); break;
+        case 2:  rc = launch_assign_fast_k<2>(a, c16, bias, packed, lds_cw, prune, block, grid, lds, st); break;
+        case 4:  rc = launch_assign_fast_k<4>(a, c16, bias, packed, lds_cw, prune, block, grid, lds, st); break;
+        case 6:  rc = launch_assign_fast_k<6>(a, c16, bias, packed, lds_cw, prune, block, grid, lds, st); break;
+        case 8:  rc = launch_assign_fast_k<8>(a, c16, bias, packed, lds_cw, prune, block, grid, lds, st); break;
+        case 12: rc = launch_assign_fast_k<12>(a, c16, bias, packed, lds_cw, prune, block, grid, lds, st); break;
+        case 16: rc = launch_assign_fast_k<16>(a, c16, bias, packed, lds_cw, prune, block, grid, lds, st); break;
+        case 24: rc = launch_assign_fast_k<24>(a, c16, bias, packed, lds_cw, prune, block, grid, lds, st); break;
+        case 32: rc = launch_assign_fast_k<32>(a, c16, bias, packed, lds_cw, prune, block, grid, lds, st); break;
+        case 48: rc = launch_assign_fast_k<48>(a, c16, bias, packed, lds_cw, prune, block, grid, lds, st); break;
+        case 64: rc = launch_assign_fast_k<64>(a, c16, bias, packed, lds_cw, prune, block, grid, lds, st); break;
+        case 96: rc = launch_assign_fast_k<96>(a, c16, bias, packed, lds_cw, prune, block, grid, lds, st); break;
         default: return fail(VQ_E_UNSUPPORTED, "no fast kernel for d=%d", d);
     }
     if (rc) return rc;
-    // fix-up: a fixed grid strides over the queue (its length is only known on the device); small
-    // codebooks are staged in LDS, one 1024-thread workgroup per CU
+    // fix-up: a fixed grid strides over the sub-queues (their lengths are only known on the device);
+    // small codebooks are staged in LDS, one 1024-thread workgroup per CU
     const size_t cb_bytes = (size_t)K * d * sizeof(double);
     if (cb_bytes <= 64 * 1024) {
         if (cb_bytes > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fixup<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)cb_bytes));
-        hipLaunchKernelGGL(k_fixup<true>, dim3(di.cus), dim3(1024), cb_bytes, st, blocks, d, cbT, K, queue, qcount,
-                           labels, min_dist, ksums, kcounts);
+        hipLaunchKernelGGL(k_fixup<true>, dim3((di.cus + 3) / 4 * 4), dim3(1024), cb_bytes, st, blocks, d, cbT, K, queue,
+                           qcount, qcap, labels, min_dist);
     } else {
-        hipLaunchKernelGGL(k_fixup<false>, dim3(di.cus * 4), dim3(256), 0, st, blocks, d, cbT, K, queue, qcount, labels,
-                           min_dist, ksums, kcounts);
+        hipLaunchKernelGGL(k_fixup<false>, dim3((di.cus * 4 + 15) / 16 * 16), dim3(256), 0, st, blocks, d, cbT, K, queue,
+                           qcount, qcap, labels, min_dist);
     }
     LAUNCH_CHECK("k_fixup");
-    if (rows_pass) {
-        const int V = d >= WAVE ? 1 : WAVE / d;
-        hipLaunchKernelGGL(k_accum_rows, dim3(grid_for((N + V - 1) / V, 4, 16384)), dim3(256), 0, st, blocks, N, d, labels,
-                           K, sums, counts);
-        LAUNCH_CHECK("k_accum_rows");
+    return VQ_OK;
+}
+
+// Whether the [K][d+1] table of k_accum_dist fits the LDS of one workgroup.
+bool accum_table_fits(int K, int d, const DeviceInfo &di) { return (size_t)K * (d + 1) * 4 + 16 <= di.lds_per_block; }
+
+// Per-cluster sums / counts for a finished labelling, plus (want_dist) the fp64 distance of every
+// vector to its codeword: the LDS-table kernel when the table fits, else coalesced global atomics.
+// When the table does not fit, distances are NOT computed here (the caller asks the search for them).
+int run_accum(const uint8_t *blocks, int64_t N, int d, const int32_t *labels, const double *cb, int K,
+              unsigned long long *sums, unsigned long long *counts, double *min_dist, hipStream_t st) {
+    DeviceInfo di;
+    int rc = device_info(di);
+    if (rc) return rc;
+    if (accum_table_fits(K, d, di)) {
+        const size_t tab = ((size_t)K * (d + 1) + 3) / 4 * 16;
+        const size_t cbb = (size_t)K * d * 8;
+        const bool cb_lds = min_dist != nullptr && tab + cbb <= 64 * 1024;
+        const size_t lds = tab + (cb_lds ? cbb : 0);
+        int wg_per_cu = (int)((160 * 1024) / (lds > 0 ? lds : 1));
+        if (wg_per_cu > 8) wg_per_cu = 8;
+        if (wg_per_cu < 1) wg_per_cu = 1;
+        const int grid = grid_for(N, 256, di.cus * wg_per_cu);
+        const bool vec16 = d == 16 && (reinterpret_cast<uintptr_t>(blocks) & 15) == 0;
+#define VQ_LAUNCH_ACCUM(V, C)                                                                                          \
+    do {                                                                                                               \
+        auto kern = k_accum_dist<V, C>;                                                                                \
+        if (lds > 48 * 1024)                                                                                           \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                          \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, blocks, N, d, labels, cb, K, sums, counts, min_dist); \
+    } while (0)
+        if (vec16 && cb_lds) VQ_LAUNCH_ACCUM(true, true);
+        else if (vec16) VQ_LAUNCH_ACCUM(true, false);
+        else if (cb_lds) VQ_LAUNCH_ACCUM(false, true);
+        else VQ_LAUNCH_ACCUM(false, false);
+#undef VQ_LAUNCH_ACCUM
+        LAUNCH_CHECK("k_accum_dist");
+        return VQ_OK;
     }
+    const int V = d >= WAVE ? 1 : WAVE / d;
+    hipLaunchKernelGGL(k_accum_rows, dim3(grid_for((N + V - 1) / V, 4, 16384)), dim3(256), 0, st, blocks, N, d, labels, K,
+                       sums, counts);
+    LAUNCH_CHECK("k_accum_rows");
     return VQ_OK;
 }
 
@@ -1494,7 +1833,7 @@ int vq_encode_l1(const uint8_t *blocks, int64_t N, int d, const double *cb, int 
         if (rc) return rc;
         rc = run_prepare(cb, K, d, ws, st);
         if (rc) return rc;
-        return run_fast(blocks, N, d, cb, K, labels, min_dist, nullptr, nullptr, ws, st);
+        return run_fast(blocks, nullptr, N, d, cb, K, labels, min_dist, ws, st);
     }
     int grid = grid_for(N, 256, 16384);
     hipLaunchKernelGGL(k_assign_exact, dim3(grid), dim3(256), 0, st, blocks, N, d, cb, K, labels, min_dist);
@@ -1512,8 +1851,39 @@ int vq_codebook_prepare(const double *cb, int K, int d, void *ws, size_t ws_byte
     return run_prepare(cb, K, d, ws, static_cast<hipStream_t>(stream));
 }
 
-int vq_encode_l1_prepared(const uint8_t *blocks, int64_t N, int d, const double *cb, int K, int32_t *labels,
-                          double *min_dist, void *ws, size_t ws_bytes, void *stream) {
+size_t vq_sorted_bytes(int d, int64_t N) {
+    if (d <= 0 || N < 0) return 0;
+    return sorted_layout(d, N).total;
+}
+
+int vq_prune_supported(int K, int d) { return (K > 0 && d > 0 && prune_supported(K, d)) ? 1 : 0; }
+
+int vq_blocks_sort(const uint8_t *blocks, int64_t N, int d, void *sorted, size_t sorted_bytes, void *stream) {
+    if (N < 0 || d <= 0) return fail(VQ_E_INVALID, "need N >= 0 and d > 0");
+    if (d > MAX_D_FAST) return fail(VQ_E_UNSUPPORTED, "d=%d is beyond the fast kernels", d);
+    if (N > 0xfffffff0LL) return fail(VQ_E_UNSUPPORTED, "N=%lld exceeds 2^32 per call", (long long)N);
+    if (N == 0) return VQ_OK;
+    if (!blocks || !sorted) return fail(VQ_E_INVALID, "null pointer");
+    SortedLayout SL = sorted_layout(d, N);
+    if (sorted_bytes < SL.total) return fail(VQ_E_WORKSPACE, "sorted buffer of %zu bytes needed, %zu given", SL.total, sorted_bytes);
+    if (reinterpret_cast<uintptr_t>(sorted) & 15) return fail(VQ_E_INVALID, "sorted buffer must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char *sp = static_cast<char *>(sorted);
+    uint8_t *rows = reinterpret_cast<uint8_t *>(sp + SL.rows);
+    uint16_t *perm = reinterpret_cast<uint16_t *>(sp + SL.perm);
+    int bshift = 0;                                        // element sums 0 .. 255 * d into SORT_BUCKETS buckets
+    while (((255u * (uint32_t)d) >> bshift) >= (uint32_t)SORT_BUCKETS) ++bshift;
+    const int grid = (int)((N + SORT_WIN - 1) / SORT_WIN);
+    if (d == 16 && (reinterpret_cast<uintptr_t>(blocks) & 15) == 0)
+        hipLaunchKernelGGL(k_window_sort<true>, dim3(grid), dim3(1024), 0, st, blocks, N, d, bshift, rows, perm);
+    else
+        hipLaunchKernelGGL(k_window_sort<false>, dim3(grid), dim3(1024), 0, st, blocks, N, d, bshift, rows, perm);
+    LAUNCH_CHECK("k_window_sort");
+    return VQ_OK;
+}
+
+int vq_encode_l1_prepared(const uint8_t *blocks, const void *sorted, int64_t N, int d, const double *cb, int K,
+                          int32_t *labels, double *min_dist, void *ws, size_t ws_bytes, void *stream) {
     int rc = check_common(blocks, N, d, cb, K);
     if (rc) return rc;
     if (!fast_supported(d)) return fail(VQ_E_UNSUPPORTED, "d=%d is beyond the prepared (fast) kernels", d);
@@ -1522,7 +1892,7 @@ int vq_encode_l1_prepared(const uint8_t *blocks, int64_t N, int d, const double 
     if (rc) return rc;
     if (N == 0) return VQ_OK;
     if (!labels) return fail(VQ_E_INVALID, "null labels pointer");
-    return run_fast(blocks, N, d, cb, K, labels, min_dist, nullptr, nullptr, ws, static_cast<hipStream_t>(stream));
+    return run_fast(blocks, sorted, N, d, cb, K, labels, min_dist, ws, static_cast<hipStream_t>(stream));
 }
 
 int vq_accum_labels(const uint8_t *blocks, int64_t N, int d, const int32_t *labels, int K, uint64_t *sums,
@@ -1530,13 +1900,8 @@ int vq_accum_labels(const uint8_t *blocks, int64_t N, int d, const int32_t *labe
     if (N < 0 || d <= 0 || K <= 0) return fail(VQ_E_INVALID, "need N >= 0, d > 0, K > 0");
     if (N == 0) return VQ_OK;
     if (!blocks || !labels || !sums || !counts) return fail(VQ_E_INVALID, "null pointer");
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const int V = d >= WAVE ? 1 : WAVE / d;
-    int grid = grid_for((N + V - 1) / V, 4, 16384);
-    hipLaunchKernelGGL(k_accum_rows, dim3(grid), dim3(256), 0, st, blocks, N, d, labels, K,
-                       reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts));
-    LAUNCH_CHECK("k_accum_rows");
-    return VQ_OK;
+    return run_accum(blocks, N, d, labels, nullptr, K, reinterpret_cast<unsigned long long *>(sums),
+                     reinterpret_cast<unsigned long long *>(counts), nullptr, static_cast<hipStream_t>(stream));
 }
 
 int vq_numpy_sum_f64(const double *v, int64_t N, double *out, double *chunk_sums, void *stream) {
@@ -1545,9 +1910,9 @@ int vq_numpy_sum_f64(const double *v, int64_t N, double *out, double *chunk_sums
     return run_numpy_sum(v, N, chunk_sums, out, static_cast<hipStream_t>(stream));
 }
 
-int vq_lbg_accum(const uint8_t *blocks, int64_t N, int d, const double *cb, int K, uint64_t *sums, uint64_t *counts,
-                 int32_t *labels, double *min_dist, double *dist_sum, double *chunk_sums, int mode, void *ws,
-                 size_t ws_bytes, void *stream) {
+int vq_lbg_accum(const uint8_t *blocks, const void *sorted, int64_t N, int d, const double *cb, int K, uint64_t *sums,
+                 uint64_t *counts, int32_t *labels, double *min_dist, double *dist_sum, double *chunk_sums, int mode,
+                 void *ws, size_t ws_bytes, void *stream) {
     int rc = check_common(blocks, N, d, cb, K);
     if (rc) return rc;
     if (!sums || !counts || !dist_sum) return fail(VQ_E_INVALID, "null sums, counts or dist_sum pointer");
@@ -1560,19 +1925,24 @@ int vq_lbg_accum(const uint8_t *blocks, int64_t N, int d, const double *cb, int 
     unsigned long long *s64 = reinterpret_cast<unsigned long long *>(sums);
     unsigned long long *c64 = reinterpret_cast<unsigned long long *>(counts);
     if (N > 0) {
+        DeviceInfo di;
+        rc = device_info(di);
+        if (rc) return rc;
+        // the accumulation pass also evaluates the distances when its table fits the LDS
+        const bool dist_in_accum = accum_table_fits(K, d, di);
         if (mode == VQ_MODE_FAST && fast_supported(d)) {
             rc = run_prepare(cb, K, d, ws, st);
             if (rc) return rc;
-            rc = run_fast(blocks, N, d, cb, K, labels, min_dist, s64, c64, ws, st);
+            rc = run_fast(blocks, sorted, N, d, cb, K, labels, dist_in_accum ? nullptr : min_dist, ws, st);
+            if (rc) return rc;
+            rc = run_accum(blocks, N, d, labels, cb, K, s64, c64, dist_in_accum ? min_dist : nullptr, st);
             if (rc) return rc;
         } else {
             int grid = grid_for(N, 256, 16384);
             hipLaunchKernelGGL(k_assign_exact, dim3(grid), dim3(256), 0, st, blocks, N, d, cb, K, labels, min_dist);
             LAUNCH_CHECK("k_assign_exact");
-            const int V = d >= WAVE ? 1 : WAVE / d;
-            hipLaunchKernelGGL(k_accum_rows, dim3(grid_for((N + V - 1) / V, 4, 16384)), dim3(256), 0, st, blocks, N, d,
-                               labels, K, s64, c64);
-            LAUNCH_CHECK("k_accum_rows");
+            rc = run_accum(blocks, N, d, labels, cb, K, s64, c64, nullptr, st);
+            if (rc) return rc;
         }
     }
     double *cs = chunk_sums ? chunk_sums

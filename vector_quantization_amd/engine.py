@@ -80,13 +80,40 @@ class HipEngine:
         return sums
 
     # -- nearest codeword (VQ_Full.py:124-125) -----------------------------------------------------
-    def encode(self, blocks, cb, want_dist=False, mode=None):
+    def sort_blocks(self, blocks, out=None):
+        """Window-sorted copy of the block vectors for the pruned search (a second layout of
+        self.blocks, VQ_Full.py:51-57); pass the result as `sorted=` to encode / encode_prepared /
+        lbg_accum together with the same blocks.  Returns None for dimensions the fast kernels do
+        not serve."""
+        N, d = blocks.shape
+        if d > 192 or N == 0:
+            return None
+        need = lib.vq_sorted_bytes(int(d), int(N))
+        if out is None or out.numel() < need:
+            out = torch.empty(need, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib.vq_blocks_sort(_ptr(blocks), N, d, _ptr(out), out.numel(), self._stream()), "vq_blocks_sort")
+        return out
+
+    @staticmethod
+    def prune_supported(K, d):
+        return bool(lib.vq_prune_supported(int(K), int(d)))
+
+    def encode(self, blocks, cb, want_dist=False, mode=None, sorted=None):
         N, d = blocks.shape
         cb = self._dev(cb, torch.float64)
         K = cb.shape[0]
         labels = torch.empty(N, dtype=torch.int32, device=self.device)
         mind = torch.empty(N, dtype=torch.float64, device=self.device) if want_dist else None
         ws = self._workspace(K, d, N)
+        use_mode = self.mode if mode is None else mode
+        if sorted is not None and use_mode == VQ_MODE_FAST and N > 0 and self.prune_supported(K, d):
+            with torch.cuda.device(self.device):
+                check(lib.vq_codebook_prepare(_ptr(cb), K, d, _ptr(ws), ws.numel(), self._stream()),
+                      "vq_codebook_prepare")
+                check(lib.vq_encode_l1_prepared(_ptr(blocks), _ptr(sorted), N, d, _ptr(cb), K, _ptr(labels), _ptr(mind),
+                                                _ptr(ws), ws.numel(), self._stream()), "vq_encode_l1_prepared")
+            return (labels, mind) if want_dist else labels
         with torch.cuda.device(self.device):
             check(lib.vq_encode_l1(_ptr(blocks), N, d, _ptr(cb), K, _ptr(labels), _ptr(mind),
                                    self.mode if mode is None else mode, _ptr(ws), ws.numel(), self._stream()),
@@ -105,7 +132,7 @@ class HipEngine:
                   "vq_codebook_prepare")
         return (cb, ws)
 
-    def encode_prepared(self, blocks, prepared, labels=None, want_dist=False):
+    def encode_prepared(self, blocks, prepared, labels=None, want_dist=False, sorted=None):
         cb, ws = prepared
         N, d = blocks.shape
         K = cb.shape[0]
@@ -113,12 +140,12 @@ class HipEngine:
             labels = torch.empty(N, dtype=torch.int32, device=self.device)
         mind = torch.empty(N, dtype=torch.float64, device=self.device) if want_dist else None
         with torch.cuda.device(self.device):
-            check(lib.vq_encode_l1_prepared(_ptr(blocks), N, d, _ptr(cb), K, _ptr(labels), _ptr(mind), _ptr(ws),
-                                            ws.numel(), self._stream()), "vq_encode_l1_prepared")
+            check(lib.vq_encode_l1_prepared(_ptr(blocks), _ptr(sorted), N, d, _ptr(cb), K, _ptr(labels), _ptr(mind),
+                                            _ptr(ws), ws.numel(), self._stream()), "vq_encode_l1_prepared")
         return (labels, mind) if want_dist else labels
 
     # -- fused LBG assignment + accumulation (VQ_Full.py:77-90) -------------------------------------
-    def lbg_accum(self, blocks, cb, want_labels=False, mode=None, want_chunks=False):
+    def lbg_accum(self, blocks, cb, want_labels=False, mode=None, want_chunks=False, sorted=None):
         """Returns (acc, dist_sum[, labels][, chunk_sums]); acc is one int64 buffer
         [K*d sums | K counts] so that a multi-GPU job can all-reduce it in one collective.  dist_sum
         is the sum of the winning distances in numpy's summation order."""
@@ -136,7 +163,7 @@ class HipEngine:
         ws = self._workspace(K, d, N)
         sums, counts = acc[: K * d], acc[K * d:]
         with torch.cuda.device(self.device):
-            check(lib.vq_lbg_accum(_ptr(blocks), N, d, _ptr(cb), K, _ptr(sums), _ptr(counts), _ptr(labels),
+            check(lib.vq_lbg_accum(_ptr(blocks), _ptr(sorted), N, d, _ptr(cb), K, _ptr(sums), _ptr(counts), _ptr(labels),
                                    _ptr(self._dist_scratch), _ptr(dist), _ptr(chunks),
                                    self.mode if mode is None else mode, _ptr(ws), ws.numel(), self._stream()),
                   "vq_lbg_accum")

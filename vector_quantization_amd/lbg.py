@@ -107,17 +107,18 @@ def initial_centroid(engine, blocks, group=None):
     return centroid, n_total
 
 
-def lbg_iteration(engine, blocks, cb, n_total, group=None, shard_info=None):
-    """One pass of VQ_Full.py:77-90.  Returns (new codebook, distortion as a Python float)."""
+def lbg_iteration(engine, blocks, cb, n_total, group=None, shard_info=None, sorted=None):
+    """One pass of VQ_Full.py:77-90.  Returns (new codebook, distortion as a Python float).
+    sorted: engine.sort_blocks(blocks), built once for all iterations (optional)."""
     if group is None:
-        acc, dist = engine.lbg_accum(blocks, cb)
+        acc, dist = engine.lbg_accum(blocks, cb, sorted=sorted)
         new_cb = engine.lbg_finalize(acc, cb)      # enqueued before the host waits for the distance sum
         total = float(dist.item())
     else:
         if shard_info is None:
             shard_info = shards_chunk_aligned(blocks.shape[0], group)
         aligned, sizes = shard_info
-        acc, dist, chunks = engine.lbg_accum(blocks, cb, want_chunks=True)
+        acc, dist, chunks = engine.lbg_accum(blocks, cb, want_chunks=True, sorted=sorted)
         _allreduce_sum_(acc, group)
         new_cb = engine.lbg_finalize(acc, cb)
         total = _global_distance_sum(dist, chunks, sizes, aligned, group)
@@ -125,7 +126,7 @@ def lbg_iteration(engine, blocks, cb, n_total, group=None, shard_info=None):
 
 
 def train_lbg(engine, blocks, k, epsilon=0.01, threshold=0.001, max_iterations=100, group=None, log=print,
-              iters_per_stage=None, on_converged=None):
+              iters_per_stage=None, on_converged=None, sorted=None):
     """Follows VQ_Full.py:60-98.
 
     blocks: this rank's (N_local, d) uint8 shard on the engine's device.  group: a
@@ -140,6 +141,8 @@ def train_lbg(engine, blocks, k, epsilon=0.01, threshold=0.001, max_iterations=1
             f"Invalid quantization level k={k}: cannot exceed the total number of image blocks ({n_total})."
         )
     cb = centroid
+    if sorted is None:
+        sorted = engine.sort_blocks(blocks)       # the vectors do not change: one sort serves every iteration
     shard_info = shards_chunk_aligned(blocks.shape[0], group) if group is not None else None
     iters, conv, distortions = [], [], []
     stage = 0
@@ -150,7 +153,7 @@ def train_lbg(engine, blocks, k, epsilon=0.01, threshold=0.001, max_iterations=1
         forced = None if iters_per_stage is None else int(iters_per_stage[stage])
         limit = max_iterations if forced is None else forced
         for i in range(limit):
-            cb, distortion = lbg_iteration(engine, blocks, cb, n_total, group, shard_info)
+            cb, distortion = lbg_iteration(engine, blocks, cb, n_total, group, shard_info, sorted)
             distortions.append(distortion)
             done += 1
             if forced is None and prev != float("inf"):
