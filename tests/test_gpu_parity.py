@@ -357,7 +357,7 @@ def test_encode_pruned_golden(eng, oracle, train_case):
     assert np.array_equal(got.reshape(g["labels"].shape), g["labels"])
 
 
-@pytest.mark.parametrize("K,d", [(256, 16), (64, 4), (1024, 16), (2048, 16)])
+@pytest.mark.parametrize("K,d", [(256, 16), (64, 4), (1024, 16), (2048, 16), (128, 15), (64, 11), (32, 27), (256, 3)])
 def test_lbg_iteration_pruned(eng, oracle, K, d):
     rng = np.random.default_rng(K * 3 + d)
     N = 20000

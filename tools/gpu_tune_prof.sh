@@ -19,7 +19,7 @@ for r in csv.DictReader(open(f)):
     d[(k, r["Grid_Size_X"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 out = []
 for (k, g), v in sorted(d.items()):
-    if int(g) >= 262144 and ("assign" in k or "fixup" in k or "sort" in k):
+    if int(g) >= 1024:
         out.append(f"{k}[{g}] n={len(v)} med={statistics.median(v):.1f}")
 print(name, " | ".join(out))
 PY

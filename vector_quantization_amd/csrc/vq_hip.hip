@@ -97,6 +97,9 @@ constexpr int SORT_BUCKETS = 2048;      // counting-sort buckets per window
 // the group of 64 consecutive vectors g goes to sub-queue g % NQ.  (One counter for the whole
 // launch serialises some 10^4 same-address atomics and was measured to bound the kernel.)
 constexpr int NQ = 64;
+// The fused accumulation flushes its LDS tables into NREP replicas of the [K][d+1] table (workgroup w
+// into replica w % NREP): atomics to one small table serialise on its few cache lines.
+constexpr int NREP = 32;
 inline size_t queue_cap(int64_t N) {                       // entries per sub-queue
     const size_t groups = ((size_t)N + 63) / 64;
     return (groups + NQ - 1) / NQ * 64;
@@ -112,6 +115,7 @@ struct WsLayout {
     size_t bias;       // Kpad uint32: key bias (original row index, plus the never-wins bit for duplicate rows)
     size_t c16u;       // K * dp2 uint32: the same rows in original order (scratch of the prepare kernel)
     size_t postab;     // POSTAB_WORDS uint32: sum threshold -> position in the sorted codebook
+    size_t acc_rep;    // NREP * K * (d + 1) uint64: replicas of the [sums | count] table (fused accumulation)
     size_t cbT;        // d * K doubles: transposed fp64 codebook
     size_t cb_u8;      // K * d bytes: codebook truncated to uint8 (decode)
     size_t chunks;     // ceil(N / 8192) + 1 doubles: per-chunk sums of the distance array
@@ -133,6 +137,7 @@ WsLayout ws_layout(int K, int d, int64_t N) {
     L.bias = off;     off += align_up(kpad * 4, 256);
     L.c16u = off;     off += align_up((size_t)K * dp2 * 4, 256);
     L.postab = off;   off += align_up((size_t)POSTAB_WORDS * 4, 256);
+    L.acc_rep = off;  off += (size_t)K * (d + 1) * 4 <= 40 * 1024 ? align_up((size_t)NREP * K * (d + 1) * 8, 256) : 0;
     L.cbT = off;      off += align_up((size_t)K * d * 8, 256);
     L.cb_u8 = off;    off += align_up((size_t)K * d, 256);
     L.chunks = off;   off += align_up((size_t)((N + NP_CHUNK - 1) / NP_CHUNK + 1) * 8, 256);
@@ -667,6 +672,7 @@ struct AssignArgs {
     uint32_t *queue;            // NQ sub-queues of qcap entries: indices of ambiguous vectors, in no particular order
     uint32_t *qcount;           // entries per sub-queue, counter q at qcount[16 * q] (zeroed before the launch)
     uint32_t qcap;
+    unsigned long long *acc_rep; // ACC: NREP replicas of the [K][d+1] table of [sums | count], zeroed before the launch
     int vec4;                   // 1: rows may be read as aligned 32-bit words (d % 4 == 0, base 4-byte aligned);
                                 // 2: rows are exactly 16 bytes and 16-byte aligned
     int64_t ntiles;
@@ -698,17 +704,34 @@ constexpr int tile_k_for(int dp2) { return dp2 <= 8 ? 128 : (dp2 <= 16 ? 64 : (d
 #else
 #define VQ_ASSIGN_ATTR
 #endif
-template <int DP2, int R, int KEYMODE, bool LDS_CW, bool PRUNE>
+//
+// ACC (with PRUNE): the LBG pass of VQ_Full.py:81-90 fused in.  Every unambiguous vector's bytes are
+// added to a per-workgroup LDS table [K][d+1] (sums | count), flushed with 64-bit global atomics when
+// the workgroup ends (integer sums: order-free).  The lanes of a sorted wave mostly share a handful
+// of labels, so "lane adds its own vector" would serialise on a few LDS addresses; instead a wave
+// stages its 64 rows and labels in LDS and re-reads them transposed -- 64 / EPL vectors x EPL
+// elements per instruction -- so that one atomic instruction spreads over 16+ distinct addresses.
+template <int DP2, int R, int KEYMODE, bool LDS_CW, bool PRUNE, bool ACC = false>
 __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const AssignArgs a, const uint32_t *__restrict__ c16,
                                                      const uint32_t *__restrict__ bias) {
     static_assert(!(PRUNE && LDS_CW), "pruning is built for the scalar-load variant");
-    // dynamic LDS (LDS_CW only): [2 tiles of TILE_K * DP2 words][2 x TILE_K bias words]
+    static_assert(!ACC || (PRUNE && DP2 <= 16), "the fused accumulation belongs to the pruned variant");
+    // dynamic LDS, LDS_CW: [2 tiles of TILE_K * DP2 words][2 x TILE_K bias words]
+    //              ACC:    [K * (d + 1) words of sums | count][per wave: 64 rows of EPL bytes, 64 labels]
     extern __shared__ __align__(16) uint32_t s_tab[];
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int BLOCK = blockDim.x;
     const int d = a.d, K = a.K;
     const bool want_dist = a.min_dist != nullptr;
+    constexpr int EPL = 2 * DP2;                               // staged bytes per row (elements beyond d are zero)
+    const int tabn = K * (d + 1);                              // row K of the LDS table is a dummy (never flushed)
+    uint8_t *st_rows = reinterpret_cast<uint8_t *>(s_tab + ((tabn + d + 1 + 3) & ~3)) + (tid >> 6) * (WAVE * EPL + WAVE * 4);
+    int32_t *st_lbl = reinterpret_cast<int32_t *>(st_rows + WAVE * EPL);
+    if (ACC) {
+        for (int i = tid; i < tabn; i += BLOCK) s_tab[i] = 0u;
+        __syncthreads();
+    }
 
     const uint32_t s = a.hdr->shift;
     const uint32_t emax = a.hdr->emax;
@@ -1002,7 +1025,46 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
                 if (amb)
                     a.queue[(size_t)q * a.qcap + qbase + (uint32_t)__popcll(amask & ((1ull << lane) - 1ull))] = (uint32_t)n;
             }
-            if (!valid || amb) continue;
+            const bool settled = valid && !amb;
+            if constexpr (ACC) {
+                // stage this group's rows (raw bytes) and labels (as byte offsets of their table rows; row K
+                // is a dummy that takes the vectors not settled here), then add them transposed
+#pragma unroll
+                for (int p = 0; p < DP2; p += 2) {
+                    // x >> s holds two bytes at positions 0 and 2: pick [lo.0, lo.2, hi.0, hi.2]
+                    const uint32_t w = __builtin_amdgcn_perm(x[r][p + 1] >> s, x[r][p] >> s, 0x06040200u);
+                    *reinterpret_cast<uint32_t *>(st_rows + lane * EPL + 2 * p) = w;
+                }
+                st_lbl[lane] = (settled ? idx : K) * (d + 1) * 4;
+                // the staging area belongs to this wave alone and a wave's LDS operations complete in order:
+                // only the compiler has to be kept from moving them (a fence would also wait for the
+                // global stores in flight)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                constexpr int VS = WAVE / EPL;                   // vectors per instruction
+                const int g = lane / EPL, e = lane % EPL;
+                char *tab_e = reinterpret_cast<char *>(s_tab) + 4 * e;
+                constexpr int STEPS = (WAVE + VS - 1) / VS;
+                if (d == EPL && WAVE % EPL == 0) {             // (uniform) every lane has work in every step
+#pragma unroll
+                    for (int j = 0; j < STEPS; ++j) {
+                        const int src = j * VS + g;
+                        atomicAdd(reinterpret_cast<uint32_t *>(tab_e + st_lbl[src]), (uint32_t)st_rows[src * EPL + e]);
+                    }
+                } else {                                       // padded rows, or EPL does not divide the wave
+#pragma unroll
+                    for (int j = 0; j < STEPS; ++j) {
+                        const int src = j * VS + g;
+                        const bool on = g < VS && src < WAVE && e < d;
+                        const int srcc = on ? src : 0;
+                        const int off = st_lbl[srcc];
+                        const uint32_t b = st_rows[srcc * EPL + e];
+                        if (on) atomicAdd(reinterpret_cast<uint32_t *>(tab_e + off), b);
+                    }
+                }
+                atomicAdd(&s_tab[(settled ? idx : K) * (d + 1) + d], 1u);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging area is rewritten by the next group
+            }
+            if (!settled) continue;
             a.labels[n] = idx;
             if (want_dist) {
                 const double *crow = a.cb + (size_t)idx * d;
@@ -1022,10 +1084,35 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
             }
         }
     }
+    if (ACC) {
+        __syncthreads();
+        unsigned long long *rep = a.acc_rep + (size_t)(blockIdx.x % NREP) * tabn;
+        for (int i = tid; i < tabn; i += BLOCK) {
+            const uint32_t v = s_tab[i];
+            if (v) atomicAdd(&rep[i], (unsigned long long)v);
+        }
+    }
+}
+
+// Adds the NREP replica tables of the fused accumulation into the caller's sums / counts.
+__global__ __launch_bounds__(256) void k_reduce_replicas(const unsigned long long *__restrict__ rep, int K, int d,
+                                                         unsigned long long *__restrict__ sums,
+                                                         unsigned long long *__restrict__ counts) {
+    const int tabn = K * (d + 1);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= tabn) return;
+    unsigned long long t = 0;
+#pragma unroll 8
+    for (int r = 0; r < NREP; ++r) t += rep[(size_t)r * tabn + i];
+    if (!t) return;
+    const int kk = i / (d + 1), e = i - kk * (d + 1);
+    if (e < d) sums[(size_t)kk * d + e] += t;           // no other kernel touches sums / counts while this one runs
+    else counts[kk] += t;
 }
 
 // Fix-up pass of FAST mode: every queued vector is searched again by a whole wave in sequential
-// fp64 (exact_search_wave); its label and its distance are written here.  Waves stride over the queue, so the work is
+// fp64 (exact_search_wave); its label, its distance and -- when sums is non-null -- its
+// contribution to the cluster sums are written here.  Waves stride over the queue, so the work is
 // balanced however the ambiguous vectors cluster in the image; results do not depend on queue order.
 // A wave fetches the queue entries and vector rows of four items at once (two memory round trips
 // per four items); with LDS_CB the transposed codebook is staged in LDS once per workgroup.
@@ -1034,7 +1121,9 @@ __global__ __launch_bounds__(1024) void k_fixup(const uint8_t *__restrict__ bloc
                                                 const double *__restrict__ cbT, int K,
                                                 const uint32_t *__restrict__ queue,
                                                 const uint32_t *__restrict__ qcount, uint32_t qcap,
-                                                int32_t *__restrict__ labels, double *__restrict__ min_dist) {
+                                                int32_t *__restrict__ labels, double *__restrict__ min_dist,
+                                                unsigned long long *__restrict__ sums,
+                                                unsigned long long *__restrict__ counts) {
     extern __shared__ __align__(16) double s_cbT[];
     const int lane = threadIdx.x & (WAVE - 1);
     const uint32_t waves_per_wg = blockDim.x >> 6;
@@ -1078,6 +1167,13 @@ __global__ __launch_bounds__(1024) void k_fixup(const uint8_t *__restrict__ bloc
             if (lane == 0) {
                 labels[n[t]] = ri;
                 if (min_dist) min_dist[n[t]] = rd;
+            }
+            if (sums) {
+                for (int e = lane; e < d; e += WAVE) {
+                    const unsigned v = xrow[e];
+                    if (v) atomicAdd(&sums[(size_t)ri * d + e], (unsigned long long)v);
+                }
+                if (lane == 0) atomicAdd(&counts[ri], 1ull);
             }
         }
     }
@@ -1281,7 +1377,7 @@ __global__ __launch_bounds__(256) void k_accum_rows(const uint8_t *__restrict__ 
 // evaluates sum_e |x_e - cb[label][e]| in sequential fp64 (the value VQ_Full.py:89 gathers) for
 // every vector; CB_LDS stages the fp64 codebook in LDS behind the table.  VEC16: 16-byte rows.
 template <bool VEC16, bool CB_LDS>
-__global__ __launch_bounds__(256) void k_accum_dist(const uint8_t *__restrict__ blocks, int64_t N, int d,
+__global__ __launch_bounds__(512) void k_accum_dist(const uint8_t *__restrict__ blocks, int64_t N, int d,
                                                     const int32_t *__restrict__ labels,
                                                     const double *__restrict__ cb, int K,
                                                     unsigned long long *__restrict__ sums,
@@ -1308,39 +1404,49 @@ __global__ __launch_bounds__(256) void k_accum_dist(const uint8_t *__restrict__ 
             }
         }
     };
+    // UV vectors per thread and trip: their labels and rows are requested together, so that one
+    // memory round trip serves UV vectors
+    constexpr int UV = 4;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     uint32_t trips = 0;
-    for (int64_t n0 = (int64_t)blockIdx.x * blockDim.x; n0 < N; n0 += stride) {
-        const int64_t n = n0 + tid;
-        if (n < N) {
-            const int k = labels[n];
-            if ((unsigned)k < (unsigned)K) {
-                uint32_t *t = s_acc + (size_t)k * (d + 1);
-                const double *crow = CB_LDS ? s_cb + (size_t)k * d : cb + (size_t)k * d;
-                double acc = 0.0;
-                if (VEC16) {
-                    const uint4 v = reinterpret_cast<const uint4 *>(blocks)[n];
-                    const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+    for (int64_t n0 = (int64_t)blockIdx.x * blockDim.x; n0 < N; n0 += UV * stride) {
+        int64_t n[UV];
+        int k[UV];
+        uint4 v[UV];
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const uint32_t b = (w4[e >> 2] >> (8 * (e & 3))) & 0xffu;
-                        atomicAdd(&t[e], b);
-                        if (min_dist) acc += fabs((double)b - crow[e]);
-                    }
-                } else {
-                    const uint8_t *x = blocks + (size_t)n * d;
-                    for (int e = 0; e < d; ++e) {
-                        const uint32_t b = x[e];
-                        atomicAdd(&t[e], b);
-                        if (min_dist) acc += fabs((double)b - crow[e]);
-                    }
-                }
-                atomicAdd(&t[d], 1u);
-                if (min_dist) min_dist[n] = acc;
-            }
+        for (int u = 0; u < UV; ++u) {
+            n[u] = n0 + u * stride + tid;
+            const int64_t nc = n[u] < N ? n[u] : N - 1;           // clamped: loads stay in bounds
+            k[u] = labels[nc];
+            if (VEC16) v[u] = reinterpret_cast<const uint4 *>(blocks)[nc];
         }
-        // 32-bit LDS sums hold at most 255 * 256 per trip: flush long before they can wrap
-        if ((++trips & 0xffffu) == 0) {
+#pragma unroll
+        for (int u = 0; u < UV; ++u) {
+            if (n[u] >= N || (unsigned)k[u] >= (unsigned)K) continue;
+            uint32_t *t = s_acc + (size_t)k[u] * (d + 1);
+            const double *crow = CB_LDS ? s_cb + (size_t)k[u] * d : cb + (size_t)k[u] * d;
+            double acc = 0.0;
+            if (VEC16) {
+                const uint32_t w4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const uint32_t b = (w4[e >> 2] >> (8 * (e & 3))) & 0xffu;
+                    atomicAdd(&t[e], b);
+                    if (min_dist) acc += fabs((double)b - crow[e]);
+                }
+            } else {
+                const uint8_t *x = blocks + (size_t)n[u] * d;
+                for (int e = 0; e < d; ++e) {
+                    const uint32_t b = x[e];
+                    atomicAdd(&t[e], b);
+                    if (min_dist) acc += fabs((double)b - crow[e]);
+                }
+            }
+            atomicAdd(&t[d], 1u);
+            if (min_dist) min_dist[n[u]] = acc;
+        }
+        // 32-bit LDS sums grow by at most 255 * UV * blockDim per trip: flush long before they can wrap
+        if ((++trips & 0x3fffu) == 0) {
             __syncthreads();
             flush();
             __syncthreads();
@@ -1479,11 +1585,11 @@ int grid_for(int64_t work_items, int block, int max_blocks) {
 // Vectors per lane: the scalar-load variant serves d <= 32, the LDS variant everything.
 constexpr int r_lds_for(int dp2) { return dp2 <= 32 ? 4 : 2; }
 
-template <int DP2, int KEYMODE, bool LDS_CW, bool PRUNE = false>
+template <int DP2, int KEYMODE, bool LDS_CW, bool PRUNE = false, bool ACC = false>
 int launch_assign_fast_t(const AssignArgs &a, const uint32_t *c16, const uint32_t *bias, int block, int grid,
                          size_t lds, hipStream_t st) {
     constexpr int R = PRUNE ? VQ_RP : (LDS_CW ? r_lds_for(DP2) : r_for(DP2));
-    auto kern = k_assign_fast<DP2, R, KEYMODE, LDS_CW, PRUNE>;
+    auto kern = k_assign_fast<DP2, R, KEYMODE, LDS_CW, PRUNE, ACC>;
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
@@ -1496,6 +1602,10 @@ template <int DP2>
 int launch_assign_fast_k(const AssignArgs &a, const uint32_t *c16, const uint32_t *bias, bool packed, bool lds_cw,
                          bool prune, int block, int grid, size_t lds, hipStream_t st) {
     if constexpr (DP2 <= 16) {
+        if (!lds_cw && prune && a.acc_rep) {
+            if (packed) return launch_assign_fast_t<DP2, KEY_PACKED, false, true, true>(a, c16, bias, block, grid, lds, st);
+            return launch_assign_fast_t<DP2, KEY_SPLIT, false, true, true>(a, c16, bias, block, grid, lds, st);
+        }
         if (!lds_cw && prune) {
             if (packed) return launch_assign_fast_t<DP2, KEY_PACKED, false, true>(a, c16, bias, block, grid, lds, st);
             return launch_assign_fast_t<DP2, KEY_SPLIT, false, true>(a, c16, bias, block, grid, lds, st);
@@ -1611,8 +1721,20 @@ bool prune_supported(int K, int d) {
 
 // FAST mode on a prepared workspace: the filter kernel, then the fp64 fix-up of the vectors it
 // queued.  Writes labels and, when min_dist is non-null, the winning fp64 distances.
+// LDS bytes of the fused accumulation (table + per-wave staging) for a 256-thread workgroup.
+size_t fused_acc_lds(int K, int d) {
+    const int dp2 = dp2_bucket(d);
+    return ((size_t)(K + 1) * (d + 1) + 3) / 4 * 16 + (size_t)4 * (WAVE * 2 * dp2 + WAVE * 4);
+}
+
+// Whether run_fast can accumulate sums / counts itself (pruned kernel, table within a quarter of the LDS).
+bool fused_acc_supported(const void *sorted, int K, int d) {
+    return sorted != nullptr && prune_supported(K, d) && fused_acc_lds(K, d) <= 40 * 1024;
+}
+
+// sums / counts non-null (only with fused_acc_supported): cluster sums are accumulated too.
 int run_fast(const uint8_t *blocks, const void *sorted, int64_t N, int d, const double *cb, int K, int32_t *labels,
-             double *min_dist, void *ws, hipStream_t st) {
+             double *min_dist, unsigned long long *sums, unsigned long long *counts, void *ws, hipStream_t st) {
     const int dp2 = dp2_bucket(d);
     WsLayout L = ws_layout(K, d, 0);
     char *w = static_cast<char *>(ws);
@@ -1636,7 +1758,8 @@ int run_fast(const uint8_t *blocks, const void *sorted, int64_t N, int d, const 
     const bool prune = sorted != nullptr && prune_supported(K, d);
     const int R = prune ? VQ_RP : (lds_cw ? r_lds_for(dp2) : r_for(dp2));
     const int block = 256;
-    const size_t lds = lds_cw ? (size_t)2 * tile_k_for(dp2) * (dp2 + 1) * 4 : 0;
+    if (sums && !fused_acc_supported(sorted, K, d)) return fail(VQ_E_HIP, "internal: fused accumulation is not available here");
+    const size_t lds = lds_cw ? (size_t)2 * tile_k_for(dp2) * (dp2 + 1) * 4 : (sums ? fused_acc_lds(K, d) : 0);
     const int64_t tile = (int64_t)block * R;
     const int64_t ntiles = (N + tile - 1) / tile;
     // One tile per workgroup: the dispatcher balances the chip and the last, partly filled round of
@@ -1649,6 +1772,11 @@ int run_fast(const uint8_t *blocks, const void *sorted, int64_t N, int d, const 
     a.blocks = blocks; a.N = N; a.d = d; a.cb = cb; a.K = K; a.kbits = kbits; a.hdr = hdr;
     a.labels = labels; a.min_dist = min_dist;
     a.queue = queue; a.qcount = qcount; a.qcap = qcap;
+    a.acc_rep = nullptr;
+    if (sums) {
+        a.acc_rep = reinterpret_cast<unsigned long long *>(w + L.acc_rep);
+        HIP_TRY(hipMemsetAsync(a.acc_rep, 0, (size_t)NREP * K * (d + 1) * 8, st));
+    }
     a.ntiles = ntiles;
     a.vec4 = ((d & 3) == 0) && ((reinterpret_cast<uintptr_t>(blocks) & 3) == 0);
     if (d == 16 && (reinterpret_cast<uintptr_t>(blocks) & 15) == 0) a.vec4 = 2;     // whole 16-byte rows
@@ -1687,12 +1815,17 @@ int run_fast(const uint8_t *blocks, const void *sorted, int64_t N, int d, const 
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fixup<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)cb_bytes));
         hipLaunchKernelGGL(k_fixup<true>, dim3((di.cus + 3) / 4 * 4), dim3(1024), cb_bytes, st, blocks, d, cbT, K, queue,
-                           qcount, qcap, labels, min_dist);
+                           qcount, qcap, labels, min_dist, sums, counts);
     } else {
         hipLaunchKernelGGL(k_fixup<false>, dim3((di.cus * 4 + 15) / 16 * 16), dim3(256), 0, st, blocks, d, cbT, K, queue,
-                           qcount, qcap, labels, min_dist);
+                           qcount, qcap, labels, min_dist, sums, counts);
     }
     LAUNCH_CHECK("k_fixup");
+    if (sums) {
+        hipLaunchKernelGGL(k_reduce_replicas, dim3((K * (d + 1) + 255) / 256), dim3(256), 0, st, a.acc_rep, K, d, sums,
+                           counts);
+        LAUNCH_CHECK("k_reduce_replicas");
+    }
     return VQ_OK;
 }
 
@@ -1713,9 +1846,10 @@ int run_accum(const uint8_t *blocks, int64_t N, int d, const int32_t *labels, co
         const bool cb_lds = min_dist != nullptr && tab + cbb <= 64 * 1024;
         const size_t lds = tab + (cb_lds ? cbb : 0);
         int wg_per_cu = (int)((160 * 1024) / (lds > 0 ? lds : 1));
-        if (wg_per_cu > 8) wg_per_cu = 8;
+        if (wg_per_cu > 4) wg_per_cu = 4;
         if (wg_per_cu < 1) wg_per_cu = 1;
-        const int grid = grid_for(N, 256, di.cus * wg_per_cu);
+        constexpr int ACC_BLOCK = 512;
+        const int grid = grid_for(N, ACC_BLOCK, di.cus * wg_per_cu);
         const bool vec16 = d == 16 && (reinterpret_cast<uintptr_t>(blocks) & 15) == 0;
 #define VQ_LAUNCH_ACCUM(V, C)                                                                                          \
     do {                                                                                                               \
@@ -1723,7 +1857,7 @@ int run_accum(const uint8_t *blocks, int64_t N, int d, const int32_t *labels, co
         if (lds > 48 * 1024)                                                                                           \
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                          \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, blocks, N, d, labels, cb, K, sums, counts, min_dist); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(ACC_BLOCK), lds, st, blocks, N, d, labels, cb, K, sums, counts, min_dist); \
     } while (0)
         if (vec16 && cb_lds) VQ_LAUNCH_ACCUM(true, true);
         else if (vec16) VQ_LAUNCH_ACCUM(true, false);
@@ -1833,7 +1967,7 @@ int vq_encode_l1(const uint8_t *blocks, int64_t N, int d, const double *cb, int 
         if (rc) return rc;
         rc = run_prepare(cb, K, d, ws, st);
         if (rc) return rc;
-        return run_fast(blocks, nullptr, N, d, cb, K, labels, min_dist, ws, st);
+        return run_fast(blocks, nullptr, N, d, cb, K, labels, min_dist, nullptr, nullptr, ws, st);
     }
     int grid = grid_for(N, 256, 16384);
     hipLaunchKernelGGL(k_assign_exact, dim3(grid), dim3(256), 0, st, blocks, N, d, cb, K, labels, min_dist);
@@ -1892,7 +2026,7 @@ int vq_encode_l1_prepared(const uint8_t *blocks, const void *sorted, int64_t N, 
     if (rc) return rc;
     if (N == 0) return VQ_OK;
     if (!labels) return fail(VQ_E_INVALID, "null labels pointer");
-    return run_fast(blocks, sorted, N, d, cb, K, labels, min_dist, ws, static_cast<hipStream_t>(stream));
+    return run_fast(blocks, sorted, N, d, cb, K, labels, min_dist, nullptr, nullptr, ws, static_cast<hipStream_t>(stream));
 }
 
 int vq_accum_labels(const uint8_t *blocks, int64_t N, int d, const int32_t *labels, int K, uint64_t *sums,
@@ -1933,10 +2067,16 @@ int vq_lbg_accum(const uint8_t *blocks, const void *sorted, int64_t N, int d, co
         if (mode == VQ_MODE_FAST && fast_supported(d)) {
             rc = run_prepare(cb, K, d, ws, st);
             if (rc) return rc;
-            rc = run_fast(blocks, sorted, N, d, cb, K, labels, dist_in_accum ? nullptr : min_dist, ws, st);
-            if (rc) return rc;
-            rc = run_accum(blocks, N, d, labels, cb, K, s64, c64, dist_in_accum ? min_dist : nullptr, st);
-            if (rc) return rc;
+            if (fused_acc_supported(sorted, K, d)) {
+                rc = run_fast(blocks, sorted, N, d, cb, K, labels, min_dist, s64, c64, ws, st);
+                if (rc) return rc;
+            } else {
+                rc = run_fast(blocks, sorted, N, d, cb, K, labels, dist_in_accum ? nullptr : min_dist, nullptr, nullptr,
+                              ws, st);
+                if (rc) return rc;
+                rc = run_accum(blocks, N, d, labels, cb, K, s64, c64, dist_in_accum ? min_dist : nullptr, st);
+                if (rc) return rc;
+            }
         } else {
             int grid = grid_for(N, 256, 16384);
             hipLaunchKernelGGL(k_assign_exact, dim3(grid), dim3(256), 0, st, blocks, N, d, cb, K, labels, min_dist);
