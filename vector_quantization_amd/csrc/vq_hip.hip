@@ -27,6 +27,7 @@
 //
 // No entry point allocates memory; scratch comes in through the workspace argument.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -652,6 +653,93 @@ __global__ __launch_bounds__(1024) void k_window_sort(const uint8_t *__restrict_
     }
 }
 
+// The same sort for rows of DW 32-bit words (d = 4 * DW <= 16, word-aligned): the window's rows are
+// placed at their sorted positions in LDS (8192 * d bytes) and written out in order, so that every
+// global access of the kernel is coalesced (a scattered store costs one L2 request per lane).
+// Dynamic LDS: [SORT_WIN * DW words of rows][SORT_WIN uint16 origins].
+template <int DW>
+__global__ __launch_bounds__(1024) void k_window_sort_lds(const uint32_t *__restrict__ blocks, int64_t N, int bshift,
+                                                          uint32_t *__restrict__ rows, uint16_t *__restrict__ perm) {
+    constexpr int T = 1024;
+    constexpr int PER = SORT_WIN / T;                       // vectors per thread
+    extern __shared__ __align__(16) uint32_t s_rows[];
+    uint16_t *s_perm = reinterpret_cast<uint16_t *>(s_rows + (size_t)SORT_WIN * DW);
+    __shared__ uint32_t s_cnt[SORT_BUCKETS];
+    __shared__ uint32_t s_wsum[T / WAVE];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
+    const int64_t w0 = (int64_t)blockIdx.x * SORT_WIN;
+    const int count = (int)((N - w0) < SORT_WIN ? (N - w0) : SORT_WIN);      // vectors in this window
+    for (int i = tid; i < SORT_BUCKETS; i += T) s_cnt[i] = 0u;
+    __syncthreads();
+    uint32_t keep[PER][DW];
+    uint32_t bucket[PER], rank[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int li = j * T + tid;
+        const int lc = li < count ? li : count - 1;         // clamped: loads stay in bounds
+        const uint32_t *src = blocks + (size_t)(w0 + lc) * DW;
+        if (DW == 4) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(src);
+            keep[j][0] = v.x; keep[j][1 % DW] = v.y; keep[j][2 % DW] = v.z; keep[j][3 % DW] = v.w;
+        } else if (DW == 2) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(src);
+            keep[j][0] = v.x; keep[j][1 % DW] = v.y;
+        } else {
+#pragma unroll
+            for (int w = 0; w < DW; ++w) keep[j][w] = src[w];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int li = j * T + tid;
+        uint32_t sum = 0;
+#pragma unroll
+        for (int w = 0; w < DW; ++w) sum = __builtin_amdgcn_sad_u8(keep[j][w], 0u, sum);
+        bucket[j] = sum >> bshift;
+        rank[j] = li < count ? atomicAdd(&s_cnt[bucket[j]], 1u) : 0u;
+    }
+    __syncthreads();
+    // exclusive scan of the bucket counts: two buckets per thread, wave scan, then the wave totals
+    const uint32_t c0 = s_cnt[2 * tid], c1 = s_cnt[2 * tid + 1];
+    uint32_t incl = c0 + c1;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, WAVE);
+        if (lane >= off) incl += o;
+    }
+    if (lane == WAVE - 1) s_wsum[wv] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int i = 0; i < wv; ++i) wbase += s_wsum[i];
+    const uint32_t excl = wbase + incl - (c0 + c1);
+    __syncthreads();
+    s_cnt[2 * tid] = excl;
+    s_cnt[2 * tid + 1] = excl + c0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int li = j * T + tid;
+        if (li < count) {
+            const uint32_t slot = s_cnt[bucket[j]] + rank[j];            // < count
+#pragma unroll
+            for (int w = 0; w < DW; ++w) s_rows[(size_t)slot * DW + w] = keep[j][w];
+            s_perm[slot] = (uint16_t)li;
+        }
+    }
+    __syncthreads();
+    // write the window out in order
+    uint32_t *orow = rows + (size_t)w0 * DW;
+    for (int i = tid; i < count * DW; i += T) orow[i] = s_rows[i];
+    uint16_t *operm = perm + w0;
+    if ((count & 1) == 0 && (reinterpret_cast<uintptr_t>(operm) & 3) == 0) {
+        const uint32_t *sp = reinterpret_cast<const uint32_t *>(s_perm);
+        uint32_t *op = reinterpret_cast<uint32_t *>(operm);
+        for (int i = tid; i < count / 2; i += T) op[i] = sp[i];
+    } else {
+        for (int i = tid; i < count; i += T) operm[i] = s_perm[i];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // nearest codeword, FAST mode (VQ_Full.py:77-78 / :124-125), optionally fused with the
 // per-cluster accumulation of VQ_Full.py:81-90
@@ -1000,7 +1088,10 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
             const bool valid = ns < a.N;
             // index of the vector in the caller's order: the sorted copy keeps every vector inside its window
             int64_t n = ns;
-            if (PRUNE) n = (ns & ~(int64_t)(SORT_WIN - 1)) + (int64_t)origin[r];
+            if (PRUNE) {
+                n = (ns & ~(int64_t)(SORT_WIN - 1)) + (int64_t)origin[r];
+                n = n < a.N ? n : a.N - 1;                     // a `sorted` buffer that was not filled must not lead out of bounds
+            }
             uint32_t s1, s2;
             int idx;
             if (KEYMODE == KEY_PACKED) {
@@ -2008,10 +2099,41 @@ int vq_blocks_sort(const uint8_t *blocks, int64_t N, int d, void *sorted, size_t
     int bshift = 0;                                        // element sums 0 .. 255 * d into SORT_BUCKETS buckets
     while (((255u * (uint32_t)d) >> bshift) >= (uint32_t)SORT_BUCKETS) ++bshift;
     const int grid = (int)((N + SORT_WIN - 1) / SORT_WIN);
-    if (d == 16 && (reinterpret_cast<uintptr_t>(blocks) & 15) == 0)
+    const uintptr_t bp = reinterpret_cast<uintptr_t>(blocks);
+    DeviceInfo di;
+    int rc = device_info(di);
+    if (rc) return rc;
+    const size_t lds_need = (size_t)SORT_WIN * d + (size_t)SORT_WIN * 2 + (SORT_BUCKETS + 16) * 4 + 256;
+    // The LDS-staged variant has not been run on hardware yet: it is opt-in (VQ_SORT_LDS=1 in the
+    // environment) until its parity tests have passed on a GPU.
+    const char *opt = getenv("VQ_SORT_LDS");
+    const bool words = opt && opt[0] == '1' && (d % 4 == 0) && d <= 16 && (bp & 3) == 0 && (d != 16 || (bp & 15) == 0) &&
+                       (d != 8 || (bp & 7) == 0) && lds_need <= di.lds_per_block;
+    if (words) {
+        // rows staged in LDS, coalesced global traffic
+        const size_t lds = (size_t)SORT_WIN * d + (size_t)SORT_WIN * 2;
+        const uint32_t *b32 = reinterpret_cast<const uint32_t *>(blocks);
+        uint32_t *r32 = reinterpret_cast<uint32_t *>(rows);
+#define VQ_LAUNCH_SORT(DW)                                                                                          \
+    do {                                                                                                            \
+        auto kern = k_window_sort_lds<DW>;                                                                          \
+        if (lds > 48 * 1024)                                                                                        \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                       \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, st, b32, N, bshift, r32, perm);                       \
+    } while (0)
+        switch (d / 4) {
+            case 1: VQ_LAUNCH_SORT(1); break;
+            case 2: VQ_LAUNCH_SORT(2); break;
+            case 3: VQ_LAUNCH_SORT(3); break;
+            default: VQ_LAUNCH_SORT(4); break;
+        }
+#undef VQ_LAUNCH_SORT
+    } else if (d == 16 && (bp & 15) == 0) {
         hipLaunchKernelGGL(k_window_sort<true>, dim3(grid), dim3(1024), 0, st, blocks, N, d, bshift, rows, perm);
-    else
+    } else {
         hipLaunchKernelGGL(k_window_sort<false>, dim3(grid), dim3(1024), 0, st, blocks, N, d, bshift, rows, perm);
+    }
     LAUNCH_CHECK("k_window_sort");
     return VQ_OK;
 }
