@@ -135,6 +135,21 @@ def main():
     torch.cuda.synchronize(device)
     enc_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     labels_pruned = labels.clone()
+    # the two parts of the encode on their own: window sort (HBM-bound), pruned search + fix-up (VALU-bound)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for a, b in ev:
+        a.record()
+        eng.sort_blocks(blocks, out=sorted_buf)
+        b.record()
+    torch.cuda.synchronize(device)
+    sort_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for a, b in ev:
+        a.record()
+        eng.encode_prepared(blocks, prepared, labels=labels, sorted=sorted_buf)
+        b.record()
+    torch.cuda.synchronize(device)
+    search_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     for a, b in ev:
         a.record()
@@ -151,36 +166,50 @@ def main():
     torch.cuda.synchronize(device)
     dec_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     ops = 2.0 * K_CODEBOOK * d * N                  # subtract + |.|-accumulate per (vector, codeword, element)
-    achieved = ops / (enc_ms * 1e-3) / 1e12
-    # HBM bytes per launch of the same kernel on the same workload, from separate rocprofv3 --pmc passes
+    achieved = ops / (search_ms * 1e-3) / 1e12
+    # HBM bytes per launch of the same kernels on the same workload, from separate rocprofv3 --pmc passes
     # (FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as is); see profiles/
-    traffic, pmc_note = None, "no PMC summary found under profiles/"
+    traffic, pmc, pmc_note = None, None, "no PMC summary found under profiles/"
     pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_encode_summary.json")
     if os.path.isfile(pmc_path):
         with open(pmc_path) as f:
             pmc = json.load(f)
-        traffic = pmc["hbm_bytes_per_launch"]
-        pmc_note = (f"traffic and valu_busy_frac from profiles/r01_pmc_*.csv (rocprofv3 --pmc, same workload); "
-                    f"algorithmic bytes per launch = {N * (d + 4)}")
+        by_kernel = pmc["hbm_bytes_by_kernel"]
+        traffic = sum(v for k, v in by_kernel.items() if not k.startswith("k_window_sort"))
+        pmc_note = ("traffic (search + fix-up launches), valu_busy_frac and evaluated_pair_frac from profiles/r01_pmc_*.csv "
+                    f"(rocprofv3 --pmc, same workload); algorithmic bytes per launch = {N * (d + 4 + 2)} "
+                    "(row + label + 2-byte origin per vector)")
+    search_alg_bytes = N * (d + 4 + 2)
     roofline = dict(bound="valu", achieved=achieved, peak=PEAK_VALU_TOPS, unit="TFLOP/s",
                     frac=achieved / PEAK_VALU_TOPS, traffic=traffic,
-                    kernel="k_window_sort + k_assign_fast<8,4,packed,pruned> + k_fixup (vq_blocks_sort + "
-                           "vq_encode_l1_prepared)",
-                    kernel_ms=enc_ms, full_search_ms=enc_full_ms,
+                    kernel="k_assign_fast<8,4,packed,pruned> + k_fixup (the two launches of vq_encode_l1_prepared "
+                           "on window-sorted vectors)",
+                    kernel_ms=search_ms, full_search_ms=enc_full_ms,
                     full_search_achieved=ops / (enc_full_ms * 1e-3) / 1e12,
                     full_search_frac=ops / (enc_full_ms * 1e-3) / 1e12 / PEAK_VALU_TOPS,
                     full_search_labels_equal=full_equals_pruned,
                     algorithmic_ops_per_vector=2 * K_CODEBOOK * d,
-                    algorithmic_bytes_per_vector=d + 4,
-                    valu_busy_frac=(pmc["valu_busy_frac"] if traffic is not None else None),
-                    note="ops = one subtract + one |.|-accumulate per (vector, codeword, element); peak = the fp32 "
-                         "vector peak counted without FMA (157.3 / 2). The integer v_sad_u16 retires two such "
-                         "pairs per lane-instruction, so frac can exceed 1; valu_busy_frac is the share of "
-                         "SIMD issue cycles the kernel's VALU instructions occupy. The timed encode sorts each "
-                         "window of 8192 vectors by element sum and skips codewords whose element sum is "
-                         "provably too far (|sum x - sum c| <= L1 distance), so it evaluates only part of the "
-                         "K*N pairs while returning the same labels; full_search_* is the same launch pair "
-                         "without that pruning. " + pmc_note)
+                    algorithmic_bytes_per_vector=d + 4 + 2,
+                    valu_busy_frac=(pmc["full_search"]["valu_busy_frac"] if pmc else None),
+                    evaluated_pair_frac=(pmc["pruned_search"]["share_of_full_search_valu"] if pmc else None),
+                    note="ops = one subtract + one |.|-accumulate per (vector, codeword, element), counted for ALL K*N "
+                         "pairs; peak = the fp32 vector peak counted without FMA (157.3 / 2). Two effects put frac "
+                         "above 1: the integer v_sad_u16 retires two such pairs per lane-instruction, and the search "
+                         "skips every codeword whose element sum is provably too far from the vector's "
+                         "(|sum x - sum c| <= L1 distance; vectors sorted by element sum inside windows of 8192, "
+                         "codebook sorted by element sum), so it executes only evaluated_pair_frac of the "
+                         "instructions of the full search while returning the same labels. full_search_* is the "
+                         "same launch pair without that pruning and valu_busy_frac the share of SIMD issue cycles "
+                         "its VALU instructions occupy. " + pmc_note)
+    sort_alg_bytes = N * (2 * d + 2)
+    sort = dict(bound="hbm", kernel="k_window_sort (vq_blocks_sort)", kernel_ms=sort_ms,
+                achieved=sort_alg_bytes / (sort_ms * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
+                frac=sort_alg_bytes / (sort_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                traffic=(sum(v for k, v in pmc["hbm_bytes_by_kernel"].items() if k.startswith("k_window_sort"))
+                         if pmc else None),
+                algorithmic_bytes_per_vector=2 * d + 2,
+                note="reads every row once, writes it once at its sorted place plus a 2-byte origin; the scattered "
+                     "16-byte stores are the write amplification seen in traffic")
     decode_gbs = (N * (d + 4)) / (dec_ms * 1e-3) / 1e9
 
     # ---- LBG iterations (fused assign + accumulate, exchange, centroid update) ----------------------
@@ -225,7 +254,9 @@ def main():
                 "ms_per_iter": lbg_elapsed / lbg_steps * 1e3, "vectors_total": n_total,
                 "exchange": "all-reduce int64 [K*d sums | K counts] + all-gather fp64 partial" if distributed
                 else "none (1 GPU)"},
+        "encode_ms": enc_ms,
         "roofline": roofline,
+        "sort": sort,
     }
 
     if rank == 0 and world == 1 and args.cpu_sample > 0:
