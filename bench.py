@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the VQ hot path on MI355X.
 
-Workload (BASELINE config 2): one synthetic 8192 x 8192 grayscale image per GPU, 4x4 blocks
+Workload (the headline configuration): one synthetic 8192 x 8192 grayscale image per GPU, 4x4 blocks
 (N = 4 194 304 block vectors of dim 16), K = 256 codebook trained by LBG on a 2048 x 2048 crop.
 One step = encode every block vector (nearest codeword, exact labels) + decode the labels back
 to an image, inputs resident in HBM.  `value` = block vectors through that step per second,

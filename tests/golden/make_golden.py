@@ -192,7 +192,7 @@ def structured_gray(h, w, seed):
 
 
 def main():
-    # (i) BASELINE config 1: luffy.png, 2x2, k=16 (RGB, d=12)
+    # (i) the reference's own CPU-runnable case: luffy.png, 2x2, k=16 (RGB, d=12)
     run_case("luffy_2x2_k16", 2, 2, 16, path=os.path.join(REF, "luffy.png"), kat_iter=20, keep_text=True)
     # (ii) man.jpeg 4x4 k=256 (16 empty clusters) and 2x2 k=5 (K rounds up to 8)
     run_case("man_4x4_k256", 4, 4, 256, path=os.path.join(REF, "man.jpeg"), kat_iter=30)

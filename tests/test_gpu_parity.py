@@ -470,7 +470,7 @@ def test_pack_unpack(eng, oracle, K):
 
 
 # ---------------------------------------------------------------------------------------------------
-# BASELINE-size properties (no oracle at this size: size-independent checks)
+# full-size properties (no oracle at this size: size-independent checks)
 # ---------------------------------------------------------------------------------------------------
 def _structured(h, w, seed):
     g = torch.Generator(device="cuda:0").manual_seed(seed)
@@ -482,7 +482,7 @@ def _structured(h, w, seed):
 
 
 def test_full_size_encode_decode_properties(eng, oracle):
-    """8192 x 8192 grayscale, 4x4 blocks, K=256 (BASELINE config 2)."""
+    """8192 x 8192 grayscale, 4x4 blocks, K=256 (the headline configuration)."""
     from vector_quantization_amd import train_lbg
     img = _structured(8192, 8192, 0)
     blocks = eng.blocks_from_image(img, 4, 4)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Profiling target: BASELINE config 2's kernels only (no host baseline, few launches).
+"""Profiling target: the kernels of the headline workload (8192 x 8192 gray, 4x4 blocks, K=256) only (no host baseline, few launches).
 Run under rocprofv3 --kernel-trace / --pmc.  Usage: python3 tools/prof_encode.py [reps]"""
 import os
 import sys
