@@ -252,7 +252,7 @@ def main():
         "decode_frac_of_hbm_peak": decode_gbs / PEAK_HBM_GBS,
         "lbg": {"iters_per_s": lbg_steps / lbg_elapsed, "vectors_per_s": n_total * lbg_steps / lbg_elapsed,
                 "ms_per_iter": lbg_elapsed / lbg_steps * 1e3, "vectors_total": n_total,
-                "exchange": "all-reduce int64 [K*d sums | K counts] + all-gather fp64 partial" if distributed
+                "exchange": "one all-gather of int64 [K*d sums | K counts | fp64 per-chunk distance sums] per iteration" if distributed
                 else "none (1 GPU)"},
         "encode_ms": enc_ms,
         "roofline": roofline,

@@ -2,8 +2,9 @@
 
 The engine does the per-vector work on its GPU; this module owns the split schedule, the
 stop rule and -- when the block vectors are sharded over several GPUs -- the per-iteration
-exchange: one all-reduce of the integer [sums | counts] buffer and one all-gather of the fp64
-per-chunk distance sums, which every rank then adds in rank order.  Integer sums make the n-GPU
+exchange: ONE all-gather of every rank's integer [sums | counts] buffer together with its fp64
+per-chunk distance sums; every rank then adds the integers and adds the distance partials in rank
+order.  Integer sums make the n-GPU
 codebook identical to the 1-GPU one; with 8192-aligned shards the distortion (numpy's summation
 order) is identical too, so the stop rule fires at the same iteration.
 """
@@ -43,16 +44,6 @@ def _allreduce_sum_(t, group):
     return t
 
 
-def _allgather_to_host(t, group):
-    """All ranks' copies of t, stacked, as a host numpy array."""
-    import torch.distributed as dist
-    world = dist.get_world_size(group=group)
-    src = t.cpu() if _needs_host_staging(t, group) else t
-    gathered = [torch.empty_like(src) for _ in range(world)]
-    dist.all_gather(gathered, src, group=group)
-    return torch.stack(gathered).cpu().numpy()
-
-
 NP_CHUNK = 8192   # elements per pairwise-summed chunk of numpy's reduction (and of vq_numpy_sum_f64)
 
 
@@ -67,28 +58,41 @@ def shards_chunk_aligned(n_local, group):
     return all(sizes[r] % NP_CHUNK == 0 for r in holders[:-1]), sizes
 
 
-def _global_distance_sum(dist_sum, chunks, sizes, aligned, group):
-    """Sum of all ranks' winning distances.  With chunk-aligned shards it is the left-to-right total
-    of every rank's per-chunk sums in rank order -- bit for bit what one process computes on the
-    concatenated data; otherwise the per-rank sums added in rank order."""
+def _exchange(acc, dist_sum, chunks, sizes, aligned, group):
+    """The one collective of an LBG iteration.  Every rank contributes [sums | counts | its distance
+    partials] in one int64 buffer (the fp64 partials bit-cast); an all-gather hands every rank all of
+    them.  Returns (integer [sums | counts] added over the ranks, on acc's device; the global sum of
+    winning distances as a Python float).
+
+    With chunk-aligned shards the distance total is the left-to-right sum of every rank's per-chunk
+    sums in rank order -- bit for bit what one process computes on the concatenated data; otherwise
+    the per-rank sums added in rank order."""
+    import numpy as np
     import torch.distributed as dist
     world = dist.get_world_size(group=group)
+    nacc = acc.numel()
+    width = max(1, max(-(-n // NP_CHUNK) for n in sizes)) if aligned else 1
+    payload = torch.zeros(nacc + width, dtype=torch.int64, device=acc.device)
+    payload[:nacc] = acc
+    tail = payload[nacc:].view(torch.float64)
     if aligned:
-        width = max(-(-n // NP_CHUNK) for n in sizes)
-        mine = torch.zeros(max(width, 1), dtype=torch.float64, device=chunks.device)
-        mine[: chunks.numel()] = chunks
+        tail[: chunks.numel()] = chunks
     else:
-        mine = dist_sum.reshape(1)
-    host = _allgather_to_host(mine, group)
+        tail[0] = dist_sum.reshape(-1)[0]
+    src = payload.cpu() if _needs_host_staging(payload, group) else payload
+    parts = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(parts, src, group=group)
+    gathered = torch.stack(parts)                                   # (world, nacc + width)
+    acc_total = gathered[:, :nacc].sum(dim=0).to(acc.device)        # integers: any order gives the same sums
+    host = gathered[:, nacc:].contiguous().view(torch.float64).cpu().numpy()
     if aligned:
-        import numpy as np
-        parts = [host[r, : -(-sizes[r] // NP_CHUNK)] for r in range(world)]
-        seq = np.concatenate(parts) if parts else np.zeros(0)
-        return float(np.cumsum(seq)[-1]) if seq.size else 0.0      # cumsum adds strictly left to right
-    total = 0.0
-    for r in range(world):
-        total += float(host[r, 0])
-    return total
+        seq = np.concatenate([host[r, : -(-sizes[r] // NP_CHUNK)] for r in range(world)])
+        total = float(np.cumsum(seq)[-1]) if seq.size else 0.0     # cumsum adds strictly left to right
+    else:
+        total = 0.0
+        for r in range(world):
+            total += float(host[r, 0])
+    return acc_total, total
 
 
 def initial_centroid(engine, blocks, group=None):
@@ -119,9 +123,8 @@ def lbg_iteration(engine, blocks, cb, n_total, group=None, shard_info=None, sort
             shard_info = shards_chunk_aligned(blocks.shape[0], group)
         aligned, sizes = shard_info
         acc, dist, chunks = engine.lbg_accum(blocks, cb, want_chunks=True, sorted=sorted)
-        _allreduce_sum_(acc, group)
+        acc, total = _exchange(acc, dist, chunks, sizes, aligned, group)
         new_cb = engine.lbg_finalize(acc, cb)
-        total = _global_distance_sum(dist, chunks, sizes, aligned, group)
     return new_cb, total / float(n_total)
 
 
