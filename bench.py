@@ -85,6 +85,7 @@ def main():
         group = dist.group.WORLD
 
     from vector_quantization_amd import HipEngine, train_lbg, lbg_iteration
+    from vector_quantization_amd.lbg import shards_chunk_aligned
     eng = HipEngine(device)
 
     def barrier():
@@ -215,14 +216,16 @@ def main():
     # ---- LBG iterations (fused assign + accumulate, exchange, centroid update) ----------------------
     n_total = world * N
     cur = cb
+    # every rank's shard size, exchanged once (train_lbg does the same before its loop)
+    shard_info = shards_chunk_aligned(N, group) if distributed else None
     for _ in range(2):
-        cur, _ = lbg_iteration(eng, blocks, cur, n_total, group, sorted=sorted_buf)
+        cur, _ = lbg_iteration(eng, blocks, cur, n_total, group, shard_info, sorted=sorted_buf)
     barrier()
     t0 = time.perf_counter()
     lbg_steps = max(5, args.steps // 2)
     for _ in range(lbg_steps):
         # the vectors do not change between iterations: the sort made above serves all of them
-        cur, _ = lbg_iteration(eng, blocks, cur, n_total, group, sorted=sorted_buf)
+        cur, _ = lbg_iteration(eng, blocks, cur, n_total, group, shard_info, sorted=sorted_buf)
     barrier()
     lbg_elapsed = time.perf_counter() - t0
     t = torch.tensor([lbg_elapsed], dtype=torch.float64, device=device)
