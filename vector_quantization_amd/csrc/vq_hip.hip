@@ -12,13 +12,18 @@
 //      |T_k - S_k| <= E_k = sum_e |c_e * 2^s - C_e|, and the kernel knows Emax >= every E_k.
 //      Each lane tracks the two smallest keys (S_k << kbits | k); when S_second - S_first >
 //      2 * Emax the first key's codeword is the unique fp64 argmin and no fp64 work is needed.
-//   2. Re-check.  Otherwise the vector's label is stored negative, and a second kernel lets one
-//      whole wave evaluate that vector against every codeword in sequential fp64 (lanes <->
-//      codewords, coalesced reads of a transposed fp64 codebook), reducing (distance, index)
-//      lexicographically, which is numpy's first-minimum rule.
+//   2. Re-check.  Otherwise the vector's index is appended to a queue in the workspace, and a second
+//      kernel lets one whole wave evaluate each queued vector against every codeword in sequential
+//      fp64 (lanes <-> codewords, coalesced reads of a transposed fp64 codebook), reducing
+//      (distance, index) lexicographically, which is numpy's first-minimum rule.
 //   A codeword whose row is bit-identical to an earlier row can never win (ties go to the lower
 //   index), so the filter gives it a key that never competes; duplicated codewords (the twin that
 //   the split of an all-zero centroid produces) therefore do not force re-checks.
+//   Pruning.  sum_e |X_e - C_e| >= |sum_e X_e - sum_e C_e| holds exactly in integers.  With the
+//   fixed-point rows kept in ascending order of their element sum and the vectors of a wave chosen
+//   to have nearly equal element sums (vq_blocks_sort), a wave searches only the contiguous range of
+//   rows whose element sum lies within (worst best-distance so far + 2 * Emax) of its vectors' sums;
+//   every skipped codeword is provably neither the nearest nor a near-tie, so results are unchanged.
 // EXACT mode evaluates every distance in sequential fp64 and is the on-device cross-check.
 //
 // Distortion.  The per-vector winning distances go to an array, and their sum is taken in the
