@@ -51,6 +51,30 @@ def test_host_only_entry_points():
     assert rc == _lib.VQ_E_INVALID
 
 
+def test_sorted_layout_and_prune_shapes():
+    """Host arithmetic of the sorted-vector buffer and of which (K, d) the pruned search serves."""
+    from vector_quantization_amd import _lib
+    lib = _lib.lib
+    for d, n in [(16, 1), (16, 8192), (16, 8193), (4, 100000), (27, 5000), (192, 77)]:
+        rows = (n * d + 255) // 256 * 256
+        assert lib.vq_sorted_bytes(d, n) == rows + (2 * n + 255) // 256 * 256
+    assert lib.vq_sorted_bytes(16, 0) == 0 and lib.vq_sorted_bytes(0, 10) == 0
+    # scalar-load kernels only: d <= 32, 32 <= K <= 2048, fixed-point codebook within 32 KB
+    assert lib.vq_prune_supported(256, 16) == 1 and lib.vq_prune_supported(1024, 16) == 1
+    assert lib.vq_prune_supported(32, 4) == 1 and lib.vq_prune_supported(2048, 4) == 1
+    assert lib.vq_prune_supported(16, 16) == 0          # too few codewords to be worth the bookkeeping
+    assert lib.vq_prune_supported(2048, 16) == 0        # 64 KB of fixed-point rows: LDS-staged variant
+    assert lib.vq_prune_supported(256, 48) == 0 and lib.vq_prune_supported(4096, 4) == 0
+    assert lib.vq_prune_supported(0, 16) == 0 and lib.vq_prune_supported(256, 0) == 0
+    # the workspace holds one queue slot per vector (plus padding) whatever the shape
+    for n in (1, 63, 64, 65, 4096, 4097, 1 << 22):
+        assert lib.vq_workspace_bytes(64, 16, n) - lib.vq_workspace_bytes(64, 16, 0) >= 4 * n
+    rc = lib.vq_blocks_sort(None, 10, 16, None, 0, None)
+    assert rc == _lib.VQ_E_INVALID
+    rc = lib.vq_blocks_sort(ctypes.c_void_p(16), 10, 16, ctypes.c_void_p(16), 8, None)
+    assert rc == _lib.VQ_E_WORKSPACE and "sorted buffer" in _lib.last_error()
+
+
 def test_engine_refuses_to_run_without_gpu():
     import pytest
     import torch
