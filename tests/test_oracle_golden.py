@@ -123,3 +123,45 @@ def test_k_greater_than_n_raises(oracle):
     blocks = np.zeros((3, 4), dtype=np.uint8)
     with pytest.raises(ValueError):
         oracle.lbg_train(blocks, 5)
+
+
+# ---------------------------------------------------------------------------------------------------
+# the oracle against the third-party routines the reference calls (numpy / scipy are importable here)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 9, 127, 128, 129, 1000, 8191, 8192, 8193, 16384, 20000, 65537, 300001])
+def test_numpy_sum_matches_numpy_itself(oracle, n):
+    """np.mean of VQ_Full.py:90 is np.add.reduce / n: the oracle's summation order against numpy's own, bit for bit."""
+    rng = np.random.default_rng(n)
+    v = rng.random(n) * 1000.0 + rng.random(n)
+    assert oracle.numpy_sum(v) == float(np.add.reduce(v))
+    if n:
+        assert oracle.numpy_sum(v) / n == float(np.mean(v))
+
+
+@pytest.mark.parametrize("d,K", [(1, 3), (4, 16), (12, 5), (16, 256), (27, 40), (48, 33), (192, 7)])
+def test_encode_matches_scipy_cdist(oracle, d, K):
+    """cdist(..., 'cityblock') + np.argmin (VQ_Full.py:77-78, :124-125) evaluated by scipy itself."""
+    from scipy.spatial.distance import cdist
+    rng = np.random.default_rng(d * 100 + K)
+    blocks = rng.integers(0, 256, size=(700, d), dtype=np.uint8)
+    cb = rng.random((K, d)) * 255.0
+    cb[K // 2] = cb[0]                                     # a duplicated codeword: the lower index must win
+    D = cdist(blocks, cb, metric="cityblock")
+    labels, dist = oracle.encode_l1(blocks, cb, want_dist=True)
+    assert np.array_equal(labels, np.argmin(D, axis=1))
+    assert np.array_equal(dist, D[np.arange(len(blocks)), labels])
+
+
+def test_split_and_mean_match_numpy(oracle):
+    rng = np.random.default_rng(3)
+    cb = rng.random((37, 12)) * 255.0
+    assert np.array_equal(oracle.split(cb, 0.01), np.vstack([cb * (1 + 0.01), cb * (1 - 0.01)]))   # VQ_Full.py:71-73
+    blocks = rng.integers(0, 256, size=(5000, 12), dtype=np.uint8)
+    labels = rng.integers(0, 37, size=5000).astype(np.int32)
+    labels[labels == 5] = 6                                # an empty cluster keeps its old codeword
+    sums, counts = oracle.accumulate(blocks, labels, 37)
+    new = oracle.finalize(sums, counts, cb)
+    for k in range(37):
+        m = labels == k
+        want = np.mean(blocks[m], axis=0) if m.any() else cb[k]                                      # VQ_Full.py:81-86
+        assert np.array_equal(new[k], want)
