@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Builds tests/emu/_build/libvqemu.so: the kernels and the C ABI of
+vector_quantization_amd/csrc/vq_hip.hip compiled for the host against tests/emu/hip/hip_runtime.h.
+TEST INFRASTRUCTURE ONLY.  The source is used as it is, apart from three textual substitutions a
+host compiler needs (each checked to match, so that a change of the source is noticed here):
+dynamic LDS declarations become pointers into the emulated LDS, and the three kinds of inline
+gfx950 assembly become their C++ meaning (the LDS wait of a lockstep wave becomes a wave rendezvous)."""
+import os
+import re
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+SRC = os.path.join(ROOT, "vector_quantization_amd", "csrc", "vq_hip.hip")
+OUT_DIR = os.path.join(HERE, "_build")
+OUT = os.path.join(OUT_DIR, "libvqemu.so")
+
+RUNTIME = r'''
+namespace emu {
+Block *g_block = nullptr;
+unsigned char g_lds[LDS_BYTES] __attribute__((aligned(256)));
+int g_cus = 4;
+}
+thread_local emu::Idx threadIdx, blockIdx, blockDim, gridDim;
+'''
+
+
+def transform(text):
+    n_total = 0
+
+    def sub(pattern, repl, text, expect_min):
+        nonlocal n_total
+        out, n = re.subn(pattern, repl, text)
+        if n < expect_min:
+            raise SystemExit(f"emu build: pattern {pattern!r} matched {n} times, expected at least {expect_min}")
+        n_total += n
+        return out
+
+    # extern __shared__ [__align__(16)] T name[];  ->  T *name = (T *)emulated LDS
+    text = sub(r"extern __shared__ (?:__align__\(16\) )?([A-Za-z_][A-Za-z0-9_ ]*?) (s_[a-z0-9_A-Z]+)\[\];",
+               r"\1 *\2 = reinterpret_cast<\1 *>(emu::g_lds);", text, 7)
+    # v_med3_u32: the median of three
+    text = sub(r'asm\("v_med3_u32 %0, %1, %2, %3" : "=v"\(r\) : "v"\(a\), "v"\(b\), "v"\(c\)\);',
+               "r = std::max(std::min(a, b), std::min(std::max(a, b), c));", text, 1)
+    # register-class hints and LDS waits have no host meaning
+    text = sub(r'asm volatile\("" : "\+v"\(([a-z_]+)\)\);', r"(void)\1;", text, 2)
+    # "wait for my LDS operations" orders LDS traffic between the lanes of a wave that runs in lockstep;
+    # the emulated lanes are free-running threads, so it becomes a rendezvous of the wave
+    text = sub(r'asm volatile\("s_waitcnt lgkmcnt\(0\)" ::: "memory"\);', "emu::wave().bar.wait();", text, 2)
+    if "asm" in re.sub(r"//.*", "", text).replace("hipMemsetAsync", ""):
+        raise SystemExit("emu build: inline assembly this script does not know")
+    text = text.replace('#include "vq_hip.h"', '#include "vq_hip.h"\n' + RUNTIME, 1)
+    return text
+
+
+def build(force=False):
+    os.makedirs(OUT_DIR, exist_ok=True)
+    deps = [SRC, os.path.join(HERE, "hip", "hip_runtime.h"), os.path.abspath(__file__)]
+    if not force and os.path.isfile(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(p) for p in deps):
+        return OUT
+    cpp = os.path.join(OUT_DIR, "vq_hip_emu.cpp")
+    with open(cpp, "w") as f:
+        f.write(transform(open(SRC).read()))
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-pthread", "-w",
+           "-I", HERE, "-I", os.path.join(ROOT, "include"), cpp, "-o", OUT]
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,159 @@
+"""The kernels of vq_hip.hip executed on CPU threads (tests/emu) through the package's own engine,
+checked against the oracle on small inputs.  This does not replace the GPU parity tests -- the
+emulation models program logic (indexing, barriers, cross-lane exchange, atomics), not the
+hardware -- but it runs here, on every change, and under a debugger."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from emu_engine import EmuEngine, emulated_kernels
+
+
+@pytest.fixture(scope="module")
+def eng():
+    with emulated_kernels():
+        yield EmuEngine()
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _structured(rng, K, d, N, noise=10.0):
+    cb = np.clip(rng.random((K, 1)) * 255.0 + rng.normal(0, 20, (K, d)), 0, 300)
+    blocks = np.clip(cb[rng.integers(0, K, N)] + rng.normal(0, noise, (N, d)), 0, 255).astype(np.uint8)
+    return blocks, cb
+
+
+@pytest.mark.parametrize("shape,bh,bw,pad", [((33, 17, 1), 4, 4, 0), ((7, 5, 3), 2, 2, 1), ((64, 64, 1), 4, 4, 0)])
+def test_emu_blocks(eng, oracle, shape, bh, bw, pad):
+    img = np.random.default_rng(1).integers(0, 256, size=shape, dtype=np.uint8)
+    got = eng.blocks_from_image(T(img), bh, bw, pad).numpy()
+    assert np.array_equal(got, oracle.blocks_u8(img, bh, bw, pad_mode=pad))
+
+
+def _check_sorted(buf, blocks):
+    N, d = blocks.shape
+    off = (N * d + 255) // 256 * 256
+    h = buf.numpy()
+    rows, perm = h[: N * d].reshape(N, d), h[off: off + 2 * N].view(np.uint16)
+    shift = 0
+    while (255 * d) >> shift >= 2048:
+        shift += 1
+    for w0 in range(0, N, 8192):
+        n = min(8192, N - w0)
+        p = perm[w0: w0 + n].astype(np.int64)
+        assert np.array_equal(np.sort(p), np.arange(n))
+        assert np.array_equal(rows[w0: w0 + n], blocks[w0 + p])
+        assert np.all(np.diff(rows[w0: w0 + n].astype(np.int64).sum(1) >> shift) >= 0)
+
+
+@pytest.mark.parametrize("N,d", [(700, 16), (8192 + 300, 16), (3000, 4), (2500, 27)])
+def test_emu_window_sort(eng, N, d):
+    rng = np.random.default_rng(N + d)
+    blocks = np.clip(rng.integers(0, 200, size=(N, 1)) + rng.integers(0, 56, size=(N, d)), 0, 255).astype(np.uint8)
+    _check_sorted(eng.sort_blocks(T(blocks)), blocks)
+
+
+@pytest.mark.parametrize("N,d", [(700, 16), (8192 + 300, 16), (3000, 4), (2600, 12), (1900, 8)])
+def test_emu_window_sort_lds_variant(eng, N, d):
+    """The LDS-staged sort kernel (opt-in until it has run on hardware) produces a valid sorted copy."""
+    rng = np.random.default_rng(N * 3 + d)
+    blocks = np.clip(rng.integers(0, 200, size=(N, 1)) + rng.integers(0, 56, size=(N, d)), 0, 255).astype(np.uint8)
+    os.environ["VQ_SORT_LDS"] = "1"
+    try:
+        buf = eng.sort_blocks(T(blocks))
+    finally:
+        del os.environ["VQ_SORT_LDS"]
+    _check_sorted(buf, blocks)
+
+
+@pytest.mark.parametrize("K,d,N", [(40, 16, 1500), (5, 12, 700), (70, 48, 600), (300, 8, 900)])
+def test_emu_encode_full_search(eng, oracle, K, d, N):
+    rng = np.random.default_rng(K + d)
+    blocks, cb = _structured(rng, K, d, N)
+    cb[K // 2] = cb[0]                                               # duplicate row
+    want_l, want_d = oracle.encode_l1(blocks, cb, want_dist=True)
+    got_l, got_d = eng.encode(T(blocks), T(cb), want_dist=True, mode=1)
+    assert np.array_equal(got_l.numpy(), want_l)
+    assert np.array_equal(got_d.numpy(), want_d)
+
+
+@pytest.mark.parametrize("K,d,N", [(64, 16, 3000), (32, 4, 2000), (100, 11, 1500), (256, 16, 2048)])
+def test_emu_encode_pruned(eng, oracle, K, d, N):
+    rng = np.random.default_rng(K * 3 + d)
+    blocks, cb = _structured(rng, K, d, N)
+    want_l, want_d = oracle.encode_l1(blocks, cb, want_dist=True)
+    b = T(blocks)
+    got_l, got_d = eng.encode(b, T(cb), want_dist=True, mode=1, sorted=eng.sort_blocks(b))
+    assert np.array_equal(got_l.numpy(), want_l)
+    assert np.array_equal(got_d.numpy(), want_d)
+
+
+def test_emu_encode_exact_mode(eng, oracle):
+    rng = np.random.default_rng(8)
+    blocks, cb = _structured(rng, 20, 16, 600)
+    want_l, want_d = oracle.encode_l1(blocks, cb, want_dist=True)
+    got_l, got_d = eng.encode(T(blocks), T(cb), want_dist=True, mode=0)
+    assert np.array_equal(got_l.numpy(), want_l) and np.array_equal(got_d.numpy(), want_d)
+
+
+@pytest.mark.parametrize("K,d,N,use_sorted", [(64, 16, 3000, True), (32, 11, 1500, True), (48, 27, 1200, True),
+                                              (16, 16, 1500, False), (40, 48, 700, False)])
+def test_emu_lbg_iteration(eng, oracle, K, d, N, use_sorted):
+    """Fused accumulation of the pruned search (with padded staging rows) and the separate pass."""
+    rng = np.random.default_rng(K * 5 + d)
+    blocks, cb = _structured(rng, K, d, N, noise=14.0)
+    blocks[:400] = blocks[0]
+    want = oracle.lbg_iter(blocks, cb)
+    b = T(blocks)
+    srt = eng.sort_blocks(b) if use_sorted else None
+    acc, dist, labels = eng.lbg_accum(b, T(cb), want_labels=True, mode=1, sorted=srt)
+    a = acc.numpy().astype(np.uint64)
+    assert np.array_equal(labels.numpy(), want["labels"])
+    assert np.array_equal(a[: K * d].reshape(K, d), want["sums"])
+    assert np.array_equal(a[K * d:], want["counts"])
+    assert dist.item() == oracle.numpy_sum(want["min_dist"])
+    assert np.array_equal(eng.lbg_finalize(acc, T(cb)).numpy(), want["cb_out"])
+
+
+def test_emu_decode_pack_split_sum(eng, oracle):
+    rng = np.random.default_rng(2)
+    K, bh, bw, C = 20, 2, 4, 3
+    cb = rng.random((K, bh * bw * C)) * 300.0 - 20.0
+    labels = rng.integers(0, K, size=(9, 7)).astype(np.int32)
+    assert np.array_equal(eng.decode(T(labels), T(cb), bh, bw, C).numpy(), oracle.decode_u8(labels, cb, bh, bw, C))
+    flat = labels.reshape(-1)
+    packed = eng.pack_labels(T(flat), K)
+    assert np.array_equal(packed.numpy(), oracle.pack_labels(flat, K))
+    assert np.array_equal(eng.unpack_labels(packed, flat.size, K).numpy(), flat)
+    assert np.array_equal(eng.lbg_split(T(cb), 0.01).numpy(), oracle.split(cb, 0.01))
+    v = rng.random(20000) * 100.0
+    assert eng.numpy_sum(T(v)).item() == oracle.numpy_sum(v)
+    blocks = rng.integers(0, 256, size=(3000, 12), dtype=np.uint8)
+    assert np.array_equal(eng.colsum(T(blocks)).numpy().astype(np.uint64), oracle.colsum_u8(blocks))
+
+
+def test_emu_codebook_class_reproduces_reference_golden(tmp_path):
+    """Codebook.generate_codebook + compress + decompress of the package, every kernel emulated, against
+    the outputs of VQ_Full.py (golden synth_iid_128_4x4_k32; the K = 32 stage runs the pruned search
+    with the fused accumulation)."""
+    from vector_quantization_amd import Codebook
+    from vqtest_util import load_golden
+    g = load_golden("synth_iid_128_4x4_k32")
+    with emulated_kernels():
+        engine = EmuEngine()
+        cb = Codebook.from_array(g["img"], int(g["bh"]), int(g["bw"]), base_name="emu", engine=engine,
+                                 output_dir=str(tmp_path))
+        assert np.array_equal(cb.blocks, g["blocks"])
+        cb.generate_codebook(int(g["k"]))
+        assert cb.training.iters_per_stage == list(g["iters_per_stage"])
+        assert np.array_equal(np.array(cb.training.distortions), g["distortions"])
+        assert np.array_equal(cb.codebook, g["codebook"])
+        labels = cb.compress()
+        assert np.array_equal(labels, g["labels"])
+        assert np.array_equal(np.fromfile(cb.labels_bin, dtype=np.uint8), g["labels_bin"])
+        arr = Codebook.decompress(cb.labels_json, cb.codebook_json, cb.reconstructed_path, engine=engine)
+        assert np.array_equal(arr, g["decoded"])
