@@ -70,7 +70,8 @@ def test_emu_window_sort_lds_variant(eng, N, d):
     _check_sorted(buf, blocks)
 
 
-@pytest.mark.parametrize("K,d,N", [(40, 16, 1500), (5, 12, 700), (70, 48, 600), (300, 8, 900)])
+@pytest.mark.parametrize("K,d,N", [(40, 16, 1500), (5, 12, 700), (70, 48, 600), (300, 8, 900), (20, 192, 500),
+                                   (4096, 16, 1100), (33, 64, 700), (1, 16, 300)])
 def test_emu_encode_full_search(eng, oracle, K, d, N):
     rng = np.random.default_rng(K + d)
     blocks, cb = _structured(rng, K, d, N)
@@ -81,7 +82,8 @@ def test_emu_encode_full_search(eng, oracle, K, d, N):
     assert np.array_equal(got_d.numpy(), want_d)
 
 
-@pytest.mark.parametrize("K,d,N", [(64, 16, 3000), (32, 4, 2000), (100, 11, 1500), (256, 16, 2048)])
+@pytest.mark.parametrize("K,d,N", [(64, 16, 3000), (32, 4, 2000), (100, 11, 1500), (256, 16, 2048), (2048, 4, 2500),
+                                   (500, 32, 1300)])
 def test_emu_encode_pruned(eng, oracle, K, d, N):
     rng = np.random.default_rng(K * 3 + d)
     blocks, cb = _structured(rng, K, d, N)
@@ -101,7 +103,8 @@ def test_emu_encode_exact_mode(eng, oracle):
 
 
 @pytest.mark.parametrize("K,d,N,use_sorted", [(64, 16, 3000, True), (32, 11, 1500, True), (48, 27, 1200, True),
-                                              (16, 16, 1500, False), (40, 48, 700, False)])
+                                              (16, 16, 1500, False), (40, 48, 700, False), (4096, 16, 1200, False),
+                                              (2, 16, 900, True)])
 def test_emu_lbg_iteration(eng, oracle, K, d, N, use_sorted):
     """Fused accumulation of the pruned search (with padded staging rows) and the separate pass."""
     rng = np.random.default_rng(K * 5 + d)
