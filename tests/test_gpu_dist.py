@@ -1,6 +1,6 @@
 """The sharded LBG loop on the real HIP engine: two ranks (gloo rendezvous, both on cuda:0) each
 hold a shard of the block vectors; the exchange is the one bench.py and multi-GPU jobs use
-(all-reduce of integer sums/counts, all-gather of per-chunk distance sums).  The result must be
+(one all-gather of integer sums/counts and per-chunk distance sums per iteration).  The result must be
 bit-identical to the single-GPU run, including every distortion when the shards are 8192-aligned."""
 import os
 import socket
