@@ -160,3 +160,19 @@ def test_emu_codebook_class_reproduces_reference_golden(tmp_path):
         assert np.array_equal(np.fromfile(cb.labels_bin, dtype=np.uint8), g["labels_bin"])
         arr = Codebook.decompress(cb.labels_json, cb.codebook_json, cb.reconstructed_path, engine=engine)
         assert np.array_equal(arr, g["decoded"])
+
+
+@pytest.mark.parametrize("K,bh,bw,C,nr,nc", [(256, 4, 4, 1, 16, 64), (17, 2, 2, 3, 5, 8), (33, 8, 8, 3, 3, 4), (9, 3, 3, 1, 4, 5)])
+def test_emu_decode_both_kernels(eng, oracle, K, bh, bw, C, nr, nc):
+    """k_decode_u8 and the block-row variant (opt-in until it has run on hardware) give the same image."""
+    rng = np.random.default_rng(K + nr)
+    cb = rng.random((K, bh * bw * C)) * 300.0 - 20.0
+    labels = rng.integers(0, K, size=(nr, nc)).astype(np.int32)
+    want = oracle.decode_u8(labels, cb, bh, bw, C)
+    assert np.array_equal(eng.decode(T(labels), T(cb), bh, bw, C).numpy(), want)
+    os.environ["VQ_DECODE_BLOCKROWS"] = "1"
+    try:
+        got = eng.decode(T(labels), T(cb), bh, bw, C).numpy()
+    finally:
+        del os.environ["VQ_DECODE_BLOCKROWS"]
+    assert np.array_equal(got, want)

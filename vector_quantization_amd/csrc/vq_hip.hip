@@ -1614,6 +1614,57 @@ __global__ __launch_bounds__(256) void k_decode_u8(const int32_t *__restrict__ l
     }
 }
 
+// The same decode with blockIdx.y striding over BLOCK rows: a thread fetches the labels its G output
+// bytes need once and writes all bh pixel rows of that block row (k_decode_u8 fetches them again for
+// every pixel row: 4 x the label traffic at 4x4 blocks).  G = 16 or 4.
+template <int G, bool LDS_CB>
+__global__ __launch_bounds__(256) void k_decode_blockrows_u8(const int32_t *__restrict__ labels, int nr, int nc,
+                                                             const double *__restrict__ cb,
+                                                             const uint8_t *__restrict__ cb8g, int K, int bh, int bw,
+                                                             int C, uint8_t *__restrict__ img) {
+    extern __shared__ __align__(16) uint8_t s_cb8[];
+    static_assert(G == 16 || G == 4, "word-wide groups only");
+    constexpr int NW = G / 4;
+    const uint32_t seg = (uint32_t)(bw * C);
+    const uint32_t d = (uint32_t)bh * seg;
+    const uint32_t rowbytes = (uint32_t)nc * seg;
+    const uint32_t groups_per_row = rowbytes / G;
+    if (LDS_CB) {
+        const uint32_t n = (uint32_t)K * d;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s_cb8[i] = cast_u8(cb[i]);
+        __syncthreads();
+    }
+    const uint8_t *cb8 = LDS_CB ? s_cb8 : cb8g;
+    for (uint32_t r = blockIdx.y; r < (uint32_t)nr; r += gridDim.y) {
+        const int32_t *lrow = labels + (size_t)r * nc;
+        for (uint32_t xg = blockIdx.x * blockDim.x + threadIdx.x; xg < groups_per_row; xg += gridDim.x * blockDim.x) {
+            const uint32_t xb0 = xg * G;
+            uint32_t base[NW];                                  // byte offset of word w's codeword row + column
+            uint32_t q = xb0 / seg, rem = xb0 - q * seg;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                base[w] = (uint32_t)lrow[q] * d + rem;
+                rem += 4;
+                if (rem >= seg) {
+                    rem = 0;
+                    ++q;
+                }
+            }
+            for (uint32_t i = 0; i < (uint32_t)bh; ++i) {
+                uint32_t words[NW];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) words[w] = *reinterpret_cast<const uint32_t *>(cb8 + base[w] + i * seg);
+                uint8_t *o = img + (size_t)(r * (uint32_t)bh + i) * rowbytes + xb0;
+                if (G == 16) {
+                    *reinterpret_cast<uint4 *>(o) = make_uint4(words[0], words[1 % NW], words[2 % NW], words[3 % NW]);
+                } else {
+                    *reinterpret_cast<uint32_t *>(o) = words[0];
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // label bit-packing (VQ_Full.py:134-147) and its inverse
 // ------------------------------------------------------------------------------------------------
@@ -2275,6 +2326,33 @@ int vq_decode_u8(const int32_t *labels, int nr, int nc, const double *cb, int K,
     if (gy64 > (int64_t)nr * bh) gy64 = (int64_t)nr * bh;
     if (gy64 > 65535) gy64 = 65535;
     dim3 grid(gx, (unsigned)gy64);
+    // The block-row variant has not been run on hardware yet: opt-in (VQ_DECODE_BLOCKROWS=1) until its
+    // parity tests have passed on a GPU.
+    const char *opt = getenv("VQ_DECODE_BLOCKROWS");
+    if (opt && opt[0] == '1' && G != 1) {
+        int64_t gyb = ((int64_t)di.cus * 8 + gx - 1) / gx;
+        if (gyb > nr) gyb = nr;
+        if (gyb > 65535) gyb = 65535;
+        dim3 gridb(gx, (unsigned)gyb);
+#define VQ_LAUNCH_DECODE_B(GG)                                                                                      \
+    do {                                                                                                            \
+        if (lds_cb) {                                                                                               \
+            if (lds > 48 * 1024)                                                                                    \
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_decode_blockrows_u8<GG, true>),        \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
+            hipLaunchKernelGGL((k_decode_blockrows_u8<GG, true>), gridb, dim3(256), lds, st, labels, nr, nc, cb, cb8, K, \
+                               bh, bw, C, img);                                                                     \
+        } else {                                                                                                    \
+            hipLaunchKernelGGL((k_decode_blockrows_u8<GG, false>), gridb, dim3(256), 0, st, labels, nr, nc, cb, cb8, K,  \
+                               bh, bw, C, img);                                                                     \
+        }                                                                                                           \
+    } while (0)
+        if (G == 16) VQ_LAUNCH_DECODE_B(16);
+        else VQ_LAUNCH_DECODE_B(4);
+#undef VQ_LAUNCH_DECODE_B
+        LAUNCH_CHECK("k_decode_blockrows_u8");
+        return VQ_OK;
+    }
 #define VQ_LAUNCH_DECODE(GG)                                                                                        \
     do {                                                                                                            \
         if (lds_cb) {                                                                                               \
