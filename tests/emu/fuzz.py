@@ -11,7 +11,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
-from emu_engine import EmuEngine, emulated_kernels  # noqa: E402
+from emu_engine import EmuEngine, emulated_kernels, _EMU_DEVICE as GUARDED  # noqa: E402
 from oracle import vq_oracle as o  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
@@ -48,7 +48,12 @@ def make_case():
 
 
 def T(a):
-    return torch.from_numpy(np.ascontiguousarray(a))
+    """Host array -> tensor that ends at a protected page (see emu_engine): kernels that read past the
+    end of an input are caught, not only those that write past the end of an output."""
+    src = torch.from_numpy(np.ascontiguousarray(a))
+    t = torch.empty(tuple(src.shape), dtype=src.dtype, device=GUARDED)
+    t.copy_(src)
+    return t
 
 
 t_end = time.time() + budget

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from emu_engine import EmuEngine, emulated_kernels
+from emu_engine import EmuEngine, emulated_kernels, _EMU_DEVICE as GUARDED
 
 
 @pytest.fixture(scope="module")
@@ -18,7 +18,12 @@ def eng():
 
 
 def T(a):
-    return torch.from_numpy(np.ascontiguousarray(a))
+    """Host array -> tensor that ends at a protected page (see emu_engine): kernels that read past the
+    end of an input are caught, not only those that write past the end of an output."""
+    src = torch.from_numpy(np.ascontiguousarray(a))
+    t = torch.empty(tuple(src.shape), dtype=src.dtype, device=GUARDED)
+    t.copy_(src)
+    return t
 
 
 def _structured(rng, K, d, N, noise=10.0):
