@@ -181,3 +181,23 @@ def test_emu_decode_both_kernels(eng, oracle, K, bh, bw, C, nr, nc):
     finally:
         del os.environ["VQ_DECODE_BLOCKROWS"]
     assert np.array_equal(got, want)
+
+
+def test_emu_prepared_codebook_and_label_accumulation(eng, oracle):
+    """vq_codebook_prepare + vq_encode_l1_prepared on several batches, and vq_accum_labels."""
+    rng = np.random.default_rng(77)
+    K, d = 48, 16
+    _, cb = _structured(rng, K, d, 10)
+    prepared = eng.prepare_codebook(T(cb), 2000)
+    for n in (2000, 700, 1):
+        blocks, _ = _structured(rng, K, d, n)
+        blocks = np.clip(blocks.astype(np.int64) + rng.integers(-9, 10, size=blocks.shape), 0, 255).astype(np.uint8)
+        b = T(blocks)
+        want_l, want_d = oracle.encode_l1(blocks, cb, want_dist=True)
+        got_l, got_d = eng.encode_prepared(b, prepared, want_dist=True)
+        assert np.array_equal(got_l.numpy(), want_l) and np.array_equal(got_d.numpy(), want_d)
+        got_l2 = eng.encode_prepared(b, prepared, sorted=eng.sort_blocks(b))
+        assert np.array_equal(got_l2.numpy(), want_l)
+        acc = eng.accum_labels(b, got_l, K).numpy().astype(np.uint64)
+        sums, counts = oracle.accumulate(blocks, want_l, K)
+        assert np.array_equal(acc[: K * d].reshape(K, d), sums) and np.array_equal(acc[K * d:], counts)
