@@ -78,7 +78,8 @@ int vq_encode_l1(const uint8_t *blocks, int64_t N, int d, const double *cb, int 
  * Passing it to vq_encode_l1_prepared / vq_lbg_accum lets the search skip every codeword whose
  * element sum differs from the vector's by more than the best distance found (a lower bound of
  * the L1 distance), with identical results.  vq_prune_supported(K, d) tells whether a (K, d)
- * codebook is served by that search (else `sorted` is ignored). */
+ * codebook is served by that search (else `sorted` is ignored): 32 <= K <= 2048 with rows of at most
+ * 32 bytes and a fixed-point codebook of at most 32 KB. */
 size_t vq_sorted_bytes(int d, int64_t N);
 int vq_prune_supported(int K, int d);
 int vq_blocks_sort(const uint8_t *blocks, int64_t N, int d, void *sorted, size_t sorted_bytes, void *stream);

@@ -201,3 +201,27 @@ def test_emu_prepared_codebook_and_label_accumulation(eng, oracle):
         acc = eng.accum_labels(b, got_l, K).numpy().astype(np.uint64)
         sums, counts = oracle.accumulate(blocks, want_l, K)
         assert np.array_equal(acc[: K * d].reshape(K, d), sums) and np.array_equal(acc[K * d:], counts)
+
+
+@pytest.mark.parametrize("K,d,N", [(100, 48, 1500), (64, 64, 1200), (40, 33, 900)])
+def test_emu_pruned_search_for_wide_rows(eng, oracle, K, d, N):
+    """Rows of 34 .. 64 bytes (RGB 4x4 blocks) through the pruned search: opt-in (VQ_PRUNE_WIDE=1) until it
+    has run on hardware.  Encode and one LBG pass (separate accumulation) against the oracle."""
+    rng = np.random.default_rng(K + d)
+    blocks, cb = _structured(rng, K, d, N)
+    want = oracle.lbg_iter(blocks, cb)
+    b = T(blocks)
+    srt = eng.sort_blocks(b)
+    assert not eng.prune_supported(K, d)
+    os.environ["VQ_PRUNE_WIDE"] = "1"
+    try:
+        assert eng.prune_supported(K, d)
+        got_l, got_d = eng.encode(b, T(cb), want_dist=True, mode=1, sorted=srt)
+        acc, dist, labels = eng.lbg_accum(b, T(cb), want_labels=True, mode=1, sorted=srt)
+    finally:
+        del os.environ["VQ_PRUNE_WIDE"]
+    assert np.array_equal(got_l.numpy(), want["labels"]) and np.array_equal(got_d.numpy(), want["min_dist"])
+    a = acc.numpy().astype(np.uint64)
+    assert np.array_equal(labels.numpy(), want["labels"])
+    assert np.array_equal(a[: K * d].reshape(K, d), want["sums"]) and np.array_equal(a[K * d:], want["counts"])
+    assert dist.item() == oracle.numpy_sum(want["min_dist"])

@@ -1731,11 +1731,13 @@ int grid_for(int64_t work_items, int block, int max_blocks) {
 
 // Vectors per lane: the scalar-load variant serves d <= 32, the LDS variant everything.
 constexpr int r_lds_for(int dp2) { return dp2 <= 32 ? 4 : 2; }
+// Pruned search: rows beyond 32 bytes take two vectors per lane (registers).
+constexpr int r_prune_for(int dp2) { return dp2 <= 16 ? VQ_RP : 2; }
 
 template <int DP2, int KEYMODE, bool LDS_CW, bool PRUNE = false, bool ACC = false>
 int launch_assign_fast_t(const AssignArgs &a, const uint32_t *c16, const uint32_t *bias, int block, int grid,
                          size_t lds, hipStream_t st) {
-    constexpr int R = PRUNE ? VQ_RP : (LDS_CW ? r_lds_for(DP2) : r_for(DP2));
+    constexpr int R = PRUNE ? r_prune_for(DP2) : (LDS_CW ? r_lds_for(DP2) : r_for(DP2));
     auto kern = k_assign_fast<DP2, R, KEYMODE, LDS_CW, PRUNE, ACC>;
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1760,6 +1762,13 @@ int launch_assign_fast_k(const AssignArgs &a, const uint32_t *c16, const uint32_
         if (!lds_cw) {
             if (packed) return launch_assign_fast_t<DP2, KEY_PACKED, false>(a, c16, bias, block, grid, lds, st);
             return launch_assign_fast_t<DP2, KEY_SPLIT, false>(a, c16, bias, block, grid, lds, st);
+        }
+    }
+    if constexpr (DP2 > 16 && DP2 <= 32) {
+        // rows of 34 .. 64 bytes through scalar loads: the pruned search only (opt-in, see prune_supported)
+        if (!lds_cw && prune) {
+            if (packed) return launch_assign_fast_t<DP2, KEY_PACKED, false, true>(a, c16, bias, block, grid, lds, st);
+            return launch_assign_fast_t<DP2, KEY_SPLIT, false, true>(a, c16, bias, block, grid, lds, st);
         }
     }
     if constexpr (DP2 <= 32) {
@@ -1863,7 +1872,13 @@ SortedLayout sorted_layout(int d, int64_t N) {
 // which skipping codewords can pay for the bookkeeping.
 bool prune_supported(int K, int d) {
     const int dp2 = dp2_bucket(d);
-    return dp2 > 0 && K >= 32 && K <= PREP_SORT_CAP && !use_lds_codewords(K, dp2);
+    if (dp2 <= 0 || K < 32 || K > PREP_SORT_CAP) return false;
+    if (!use_lds_codewords(K, dp2)) return true;
+    // Rows of 34 .. 64 bytes (RGB 4x4 blocks are 48) whose fixed-point codebook still fits the scalar
+    // cache budget: served by the same kernel, but not run on hardware yet -- opt-in (VQ_PRUNE_WIDE=1)
+    // until its parity tests have passed on a GPU.
+    const char *opt = getenv("VQ_PRUNE_WIDE");
+    return opt && opt[0] == '1' && dp2 <= 32 && (size_t)K * dp2 * 4 <= 32 * 1024;
 }
 
 // FAST mode on a prepared workspace: the filter kernel, then the fp64 fix-up of the vectors it
@@ -1876,7 +1891,7 @@ size_t fused_acc_lds(int K, int d) {
 
 // Whether run_fast can accumulate sums / counts itself (pruned kernel, table within a quarter of the LDS).
 bool fused_acc_supported(const void *sorted, int K, int d) {
-    return sorted != nullptr && prune_supported(K, d) && fused_acc_lds(K, d) <= 40 * 1024;
+    return sorted != nullptr && prune_supported(K, d) && dp2_bucket(d) <= 16 && fused_acc_lds(K, d) <= 40 * 1024;
 }
 
 // sums / counts non-null (only with fused_acc_supported): cluster sums are accumulated too.
@@ -1901,9 +1916,9 @@ int run_fast(const uint8_t *blocks, const void *sorted, int64_t N, int d, const 
 
     const int kbits = ceil_log2(K);
     const bool packed = key_layout(K, dp2).packed;
-    const bool lds_cw = use_lds_codewords(K, dp2);
     const bool prune = sorted != nullptr && prune_supported(K, d);
-    const int R = prune ? VQ_RP : (lds_cw ? r_lds_for(dp2) : r_for(dp2));
+    const bool lds_cw = use_lds_codewords(K, dp2) && !prune;       // the pruned search always takes scalar loads
+    const int R = prune ? r_prune_for(dp2) : (lds_cw ? r_lds_for(dp2) : r_for(dp2));
     const int block = 256;
     if (sums && !fused_acc_supported(sorted, K, d)) return fail(VQ_E_HIP, "internal: fused accumulation is not available here");
     const size_t lds = lds_cw ? (size_t)2 * tile_k_for(dp2) * (dp2 + 1) * 4 : (sums ? fused_acc_lds(K, d) : 0);
