@@ -225,3 +225,27 @@ def test_emu_pruned_search_for_wide_rows(eng, oracle, K, d, N):
     assert np.array_equal(labels.numpy(), want["labels"])
     assert np.array_equal(a[: K * d].reshape(K, d), want["sums"]) and np.array_equal(a[K * d:], want["counts"])
     assert dist.item() == oracle.numpy_sum(want["min_dist"])
+
+
+@pytest.mark.parametrize("K,d,N,use_sorted", [(64, 16, 800, True), (200, 12, 500, False), (33, 48, 300, False), (2, 16, 300, False)])
+def test_emu_pruned_fixup(eng, oracle, K, d, N, use_sorted):
+    """The fix-up pass with the element-sum bound (opt-in, VQ_FIXUP_PRUNE=1) on data full of exact ties and
+    near-ties, so that most vectors are queued: labels, distances and cluster sums as the oracle's."""
+    rng = np.random.default_rng(K * 11 + d)
+    base = np.clip(rng.random((max(2, K // 3), 1)) * 255 + rng.normal(0, 15, (max(2, K // 3), d)), 0, 255)
+    cb = base[rng.integers(0, len(base), K)] + rng.choice([0.0, 0.001, -0.002, 0.5], size=(K, 1))     # twins and near-twins
+    blocks = np.clip(np.rint(cb[rng.integers(0, K, N)]) + rng.integers(-1, 2, size=(N, d)), 0, 255).astype(np.uint8)
+    want = oracle.lbg_iter(blocks, cb)
+    b = T(blocks)
+    srt = eng.sort_blocks(b) if use_sorted else None
+    os.environ["VQ_FIXUP_PRUNE"] = "1"
+    try:
+        got_l, got_d = eng.encode(b, T(cb), want_dist=True, mode=1, sorted=srt)
+        acc, dist, labels = eng.lbg_accum(b, T(cb), want_labels=True, mode=1, sorted=srt)
+    finally:
+        del os.environ["VQ_FIXUP_PRUNE"]
+    assert np.array_equal(got_l.numpy(), want["labels"]) and np.array_equal(got_d.numpy(), want["min_dist"])
+    a = acc.numpy().astype(np.uint64)
+    assert np.array_equal(labels.numpy(), want["labels"])
+    assert np.array_equal(a[: K * d].reshape(K, d), want["sums"]) and np.array_equal(a[K * d:], want["counts"])
+    assert dist.item() == oracle.numpy_sum(want["min_dist"])

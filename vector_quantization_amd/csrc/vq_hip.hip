@@ -1275,6 +1275,114 @@ __global__ __launch_bounds__(1024) void k_fixup(const uint8_t *__restrict__ bloc
     }
 }
 
+// The fix-up pass with the element-sum bound of the pruned search (needs the sorted fixed-point
+// codebook that k_prepare leaves for K <= PREP_SORT_CAP).  A wave takes one queued vector: lanes hold
+// 64 consecutive positions of the sorted codebook, starting with the chunk around the vector's own
+// element sum; after every chunk the exact best distance D gives the range of positions that can
+// still hold a codeword at distance <= D (their fixed-point element sum lies within
+// D * 2^s + Emax + 1 of the vector's, looked up in postab), and the wave takes the next chunk on
+// whichever side is not covered yet.  A skipped codeword is strictly further away than the winner,
+// so label and distance equal those of the full search, ties included (lowest codeword index).
+template <bool LDS_CB>
+__global__ __launch_bounds__(1024) void k_fixup_pruned(const uint8_t *__restrict__ blocks, int d,
+                                                       const double *__restrict__ cbT, int K,
+                                                       const uint32_t *__restrict__ queue,
+                                                       const uint32_t *__restrict__ qcount, uint32_t qcap,
+                                                       const PrepHeader *__restrict__ hdr,
+                                                       const uint32_t *__restrict__ bias,
+                                                       const uint32_t *__restrict__ postab,
+                                                       int32_t *__restrict__ labels, double *__restrict__ min_dist,
+                                                       unsigned long long *__restrict__ sums,
+                                                       unsigned long long *__restrict__ counts) {
+    extern __shared__ __align__(16) double s_cbT[];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const uint32_t waves_per_wg = blockDim.x >> 6;
+    const uint32_t wave = blockIdx.x * waves_per_wg + (threadIdx.x >> 6);
+    const uint32_t nwaves = gridDim.x * waves_per_wg / NQ;
+    const uint32_t sub = wave & (NQ - 1);
+    const uint32_t rank = wave / NQ;
+    bool any = false;
+    for (uint32_t w = 0; w < waves_per_wg; ++w) {
+        const uint32_t ww = blockIdx.x * waves_per_wg + w;
+        any = any || qcount[16 * (ww & (NQ - 1))] > ww / NQ;
+    }
+    if (!any) return;
+    if (LDS_CB) {
+        const int n = K * d;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) s_cbT[i] = cbT[i];
+        __syncthreads();
+    }
+    const uint32_t shift = hdr->shift, emax = hdr->emax, tshift = hdr->tshift, nt = hdr->nt;
+    const double scale = (double)(1u << shift);
+    const int kchunks = (K + WAVE - 1) / WAVE;                  // chunks of 64 sorted positions
+    const uint32_t count = qcount[16 * sub];
+    queue += (size_t)sub * qcap;
+    for (uint32_t i0 = rank; i0 < count; i0 += nwaves) {
+        const int64_t n = (int64_t)queue[i0];                   // wave-uniform
+        const uint8_t *xrow = blocks + (size_t)n * d;
+        // element sum of the vector in the fixed-point units of the codebook rows
+        uint32_t part = 0;
+        for (int e = lane; e < d; e += WAVE) part += xrow[e];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, WAVE);
+        const uint32_t sx = part << shift;
+        const uint32_t xv0 = lane < d ? (uint32_t)xrow[lane] : 0u;
+        double best = __builtin_huge_val();
+        int bidx = 0x7fffffff;
+        // one chunk: lane's position p -> codeword bias[p]; its exact distance in sequential fp64
+        auto chunk = [&](int c) {
+            const int p = c * WAVE + lane;
+            const int k = (int)(bias[p < K ? p : K - 1] & 0x7fffffffu);      // clamped: loads stay in bounds
+            double acc = 0.0;
+            for (int ebase = 0; ebase < d; ebase += WAVE) {
+                const int ecount = d - ebase < WAVE ? d - ebase : WAVE;
+                uint32_t xv = xv0;
+                if (ebase > 0) xv = lane < ecount ? (uint32_t)xrow[ebase + lane] : 0u;
+                for (int e0 = 0; e0 < ecount; ++e0) {
+                    const size_t off = (size_t)(ebase + e0) * K + k;
+                    const double xe = (double)__builtin_amdgcn_readlane(xv, e0);
+                    acc += fabs(xe - (LDS_CB ? s_cbT[off] : cbT[off]));
+                }
+            }
+            double cd = p < K ? acc : __builtin_huge_val();
+            int ci = p < K ? k : 0x7fffffff;
+            wave_argmin(cd, ci);                                // lexicographic (distance, codeword index)
+            if (cd < best || (cd == best && ci < bidx)) {
+                best = cd;
+                bidx = ci;
+            }
+        };
+        int ca = (int)(postab[sx >> tshift] / WAVE);
+        if (ca >= kchunks) ca = kchunks - 1;
+        int cb_ = ca + 1;                                       // chunks [ca, cb_) are done after the first call
+        chunk(ca);
+        for (;;) {
+            // positions that can still hold a codeword no further away than `best`
+            const double t = ceil(best * scale) + (double)emax + 1.0;
+            const uint32_t thr = t < 4.0e9 ? (uint32_t)t : 0xffffffffu;
+            const uint32_t lo_sum = sx > thr ? sx - thr : 0u;
+            unsigned long long ih = (((unsigned long long)sx + thr) >> tshift) + 1ull;
+            if (ih > nt + 1ull) ih = nt + 1ull;
+            const int klo = (int)postab[lo_sum >> tshift];
+            const int khi = (int)postab[ih];
+            if (klo < ca * WAVE) chunk(--ca);
+            else if (khi > cb_ * WAVE) chunk(cb_++);
+            else break;
+        }
+        if (lane == 0) {
+            labels[n] = bidx;
+            if (min_dist) min_dist[n] = best;
+        }
+        if (sums) {
+            for (int e = lane; e < d; e += WAVE) {
+                const unsigned v = xrow[e];
+                if (v) atomicAdd(&sums[(size_t)bidx * d + e], (unsigned long long)v);
+            }
+            if (lane == 0) atomicAdd(&counts[bidx], 1ull);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // numpy-order sum of an fp64 vector (the np.mean of VQ_Full.py:90 before its division)
 // ------------------------------------------------------------------------------------------------
@@ -1972,7 +2080,23 @@ int run_fast(const uint8_t *blocks, const void *sorted, int64_t N, int d, const 
     // fix-up: a fixed grid strides over the sub-queues (their lengths are only known on the device);
     // small codebooks are staged in LDS, one 1024-thread workgroup per CU
     const size_t cb_bytes = (size_t)K * d * sizeof(double);
-    if (cb_bytes <= 64 * 1024) {
+    // The pruned fix-up has not been run on hardware yet: opt-in (VQ_FIXUP_PRUNE=1) until its parity tests
+    // have passed on a GPU.  It needs the sorted codebook (K <= PREP_SORT_CAP).
+    const char *fopt = getenv("VQ_FIXUP_PRUNE");
+    if (fopt && fopt[0] == '1' && K <= PREP_SORT_CAP) {
+        const uint32_t *postab = reinterpret_cast<const uint32_t *>(w + L.postab);
+        if (cb_bytes <= 64 * 1024) {
+            if (cb_bytes > 48 * 1024)
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fixup_pruned<true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)cb_bytes));
+            hipLaunchKernelGGL(k_fixup_pruned<true>, dim3((di.cus + 3) / 4 * 4), dim3(1024), cb_bytes, st, blocks, d, cbT, K,
+                               queue, qcount, qcap, hdr, bias, postab, labels, min_dist, sums, counts);
+        } else {
+            hipLaunchKernelGGL(k_fixup_pruned<false>, dim3((di.cus * 4 + 15) / 16 * 16), dim3(256), 0, st, blocks, d, cbT, K,
+                               queue, qcount, qcap, hdr, bias, postab, labels, min_dist, sums, counts);
+        }
+        LAUNCH_CHECK("k_fixup_pruned");
+    } else if (cb_bytes <= 64 * 1024) {
         if (cb_bytes > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fixup<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)cb_bytes));
