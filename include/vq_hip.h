@@ -10,7 +10,9 @@
  *     scratch comes in through the `ws` argument (size from vq_workspace_bytes()).
  *   - Return value: 0 on success, a negative VQ_E_* code on failure; vq_last_error()
  *     returns a thread-local message for the last failure on the calling thread.
- *   - The library keeps no mutable global state; it may be called from any host thread.
+ *   - The library may be called from any host thread.  The only state it keeps between calls are
+ *     two mutex-guarded tables: device properties (queried once per device) and the buffers
+ *     vq_blocks_sort has filled (address -> N, d).
  *   - Block vectors are rows of an (N, d) uint8 matrix, d = block_h * block_w * C, element
  *     order (row-in-block, col-in-block, channel), vectors in row-major block-grid order.
  *     Codebooks are (K, d) IEEE doubles, row-major.
@@ -79,7 +81,12 @@ int vq_encode_l1(const uint8_t *blocks, int64_t N, int d, const double *cb, int 
  * element sum differs from the vector's by more than the best distance found (a lower bound of
  * the L1 distance), with identical results.  vq_prune_supported(K, d) tells whether a (K, d)
  * codebook is served by that search (else `sorted` is ignored): 32 <= K <= 2048 with rows of at most
- * 32 bytes and a fixed-point codebook of at most 32 KB. */
+ * 64 bytes and a fixed-point codebook of at most 32 KB.
+ * vq_blocks_sort ends the buffer with a (magic, N, d) header and records on the host which buffer it
+ * filled for which (N, d).  A search that is handed a `sorted` argument it has no such record of, one
+ * recorded for another N or d, or one smaller than vq_sorted_bytes(d, N), returns VQ_E_INVALID; a
+ * buffer whose header was overwritten since the sort makes the search write label -1 for every
+ * vector instead of following a stale origin map. */
 size_t vq_sorted_bytes(int d, int64_t N);
 int vq_prune_supported(int K, int d);
 int vq_blocks_sort(const uint8_t *blocks, int64_t N, int d, void *sorted, size_t sorted_bytes, void *stream);
@@ -89,10 +96,11 @@ int vq_blocks_sort(const uint8_t *blocks, int64_t N, int d, void *sorted, size_t
  * vq_encode_l1_prepared then runs VQ_MODE_FAST's two kernels (filter, fp64 fix-up) per batch.  ws must not
  * be handed to any other call in between; cb must still hold the same codebook.  Only dimensions
  * d <= 192 (the SAD filter kernels) are served; others return VQ_E_UNSUPPORTED.  `sorted` is null
- * or the buffer vq_blocks_sort filled from the same blocks. */
+ * or the buffer vq_blocks_sort filled from the same blocks (sorted_bytes: its size). */
 int vq_codebook_prepare(const double *cb, int K, int d, void *ws, size_t ws_bytes, void *stream);
-int vq_encode_l1_prepared(const uint8_t *blocks, const void *sorted, int64_t N, int d, const double *cb, int K,
-                          int32_t *labels, double *min_dist, void *ws, size_t ws_bytes, void *stream);
+int vq_encode_l1_prepared(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d,
+                          const double *cb, int K, int32_t *labels, double *min_dist, void *ws, size_t ws_bytes,
+                          void *stream);
 
 /* One LBG assignment pass, fused.  Replaces VQ_Full.py:77-90 up to the division: assigns every
  * vector as vq_encode_l1 does (labels: N int32, min_dist: N doubles, both overwritten), ADDS into
@@ -104,9 +112,9 @@ int vq_encode_l1_prepared(const uint8_t *blocks, const void *sorted, int64_t N, 
  * total of; ranks that hold consecutive, 8192-aligned shards can concatenate them to reproduce
  * the single-process value.  `sorted` is null or the buffer vq_blocks_sort filled from the same
  * blocks (used by VQ_MODE_FAST only). */
-int vq_lbg_accum(const uint8_t *blocks, const void *sorted, int64_t N, int d, const double *cb, int K,
-                 uint64_t *sums, uint64_t *counts, int32_t *labels, double *min_dist, double *dist_sum,
-                 double *chunk_sums, int mode, void *ws, size_t ws_bytes, void *stream);
+int vq_lbg_accum(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d,
+                 const double *cb, int K, uint64_t *sums, uint64_t *counts, int32_t *labels, double *min_dist,
+                 double *dist_sum, double *chunk_sums, int mode, void *ws, size_t ws_bytes, void *stream);
 
 /* Sum of an fp64 vector in the order numpy.add.reduce uses on a contiguous array (what np.mean
  * does before dividing, VQ_Full.py:90): pairwise summation -- runs of up to 128 elements with

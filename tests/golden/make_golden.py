@@ -95,7 +95,9 @@ def make_ref_codebook_from_array(img, bh, bw, base_name, outdir):
     return cb
 
 
-def run_case(name, bh, bw, k, path=None, img=None, kat_iter=None, keep_text=False):
+def run_case(name, bh, bw, k, path=None, img=None, kat_iter=None, keep_text=False, lean=False):
+    """lean: for large codebooks -- stage-end codebooks are stored as sha256 digests (the final one in
+    full), the decoded image as a digest, and the block matrix is left out (it follows from img)."""
     outdir = tempfile.mkdtemp(prefix="vqgold_")
     VQ_Full.script_dir = outdir
     rec = Recorder()
@@ -148,19 +150,28 @@ def run_case(name, bh, bw, k, path=None, img=None, kat_iter=None, keep_text=Fals
 
     out = dict(
         img=cb.img_arr, bh=bh, bw=bw, k=k, eps=0.01, thr=0.001, max_iter=100,
-        blocks=cb.blocks, n_rows=cb.n_rows, n_cols=cb.n_cols,
+        n_rows=cb.n_rows, n_cols=cb.n_cols,
         iters_per_stage=np.array(iters_per_stage, dtype=np.int64),
         stage_K=np.array(stage_K, dtype=np.int64),
         converged_iter=np.array(conv, dtype=np.int64),
         distortions=np.array([c["distortion"] for c in train], dtype=np.float64),
-        stage_end_codebooks=np.concatenate([s.ravel() for s in stage_end]) if stage_end else np.zeros(0),
-        codebook=cb.codebook, labels=labels, decoded=decoded,
+        codebook=cb.codebook, labels=labels,
         labels_bin=np.frombuffer(open(cb.labels_bin, "rb").read(), dtype=np.uint8),
         codebook_json_sha256=hashlib.sha256(open(cb.codebook_json, "rb").read()).hexdigest(),
         labels_json_sha256=hashlib.sha256(open(cb.labels_json, "rb").read()).hexdigest(),
         codebook_txt_sha256=hashlib.sha256(open(cb.codebook_txt, "rb").read()).hexdigest(),
         log=log,
     )
+    if lean:
+        out["stage_end_sha256"] = np.array([hashlib.sha256(np.ascontiguousarray(s).tobytes()).hexdigest()
+                                            for s in stage_end])
+        out["decoded_sha256"] = hashlib.sha256(np.ascontiguousarray(decoded).tobytes()).hexdigest()
+        out["mind_final"] = train[-1]["mind"] if train else np.zeros(0)
+    else:
+        out["blocks"] = cb.blocks
+        out["stage_end_codebooks"] = (np.concatenate([s.ravel() for s in stage_end]) if stage_end
+                                      else np.zeros(0))
+        out["decoded"] = decoded
     if keep_text:
         out["codebook_json_text"] = open(cb.codebook_json).read()
         out["codebook_txt_text"] = open(cb.codebook_txt).read()
@@ -263,6 +274,19 @@ def gray_case():
     print("gray_man_4x4_k16:", cb.blocks.shape, cb.codebook.shape)
 
 
+def main_large():
+    """Cases at the codebook sizes of the two large configurations, at vector counts the reference can
+    still run here (it materialises the N x K fp64 distance matrix)."""
+    # full LBG training to K = 1024 at d = 16 (grayscale 4x4): ten split stages; N = 65 536
+    g = structured_gray(1024, 1024, seed=2)
+    run_case("synth_gray_1024_4x4_k1024", 4, 4, 1024, img=g[:, :, None], kat_iter=60)
+    # RGB 8x8 blocks (d = 192), K = 4096: team.jpg, N = 19 200
+    run_case("team_8x8_k4096", 8, 8, 4096, path=os.path.join(REF, "team.jpg"), lean=True)
+
+
 if __name__ == "__main__":
-    main()
-    gray_case()
+    if len(sys.argv) > 1 and sys.argv[1] == "large":
+        main_large()
+    else:
+        main()
+        gray_case()

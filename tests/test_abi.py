@@ -57,14 +57,15 @@ def test_sorted_layout_and_prune_shapes():
     lib = _lib.lib
     for d, n in [(16, 1), (16, 8192), (16, 8193), (4, 100000), (27, 5000), (192, 77)]:
         rows = (n * d + 255) // 256 * 256
-        assert lib.vq_sorted_bytes(d, n) == rows + (2 * n + 255) // 256 * 256
+        assert lib.vq_sorted_bytes(d, n) == rows + (2 * n + 255) // 256 * 256 + 256      # rows, origins, header
     assert lib.vq_sorted_bytes(16, 0) == 0 and lib.vq_sorted_bytes(0, 10) == 0
-    # scalar-load kernels only: d <= 32, 32 <= K <= 2048, fixed-point codebook within 32 KB
+    # scalar-load kernels only: d <= 64, 32 <= K <= 2048, fixed-point codebook within 32 KB
     assert lib.vq_prune_supported(256, 16) == 1 and lib.vq_prune_supported(1024, 16) == 1
     assert lib.vq_prune_supported(32, 4) == 1 and lib.vq_prune_supported(2048, 4) == 1
     assert lib.vq_prune_supported(16, 16) == 0          # too few codewords to be worth the bookkeeping
     assert lib.vq_prune_supported(2048, 16) == 0        # 64 KB of fixed-point rows: LDS-staged variant
-    assert lib.vq_prune_supported(256, 48) == 0 and lib.vq_prune_supported(4096, 4) == 0
+    assert lib.vq_prune_supported(256, 48) == 1 and lib.vq_prune_supported(4096, 4) == 0
+    assert lib.vq_prune_supported(512, 48) == 0 and lib.vq_prune_supported(128, 64) == 1 and lib.vq_prune_supported(64, 66) == 0
     assert lib.vq_prune_supported(0, 16) == 0 and lib.vq_prune_supported(256, 0) == 0
     # the workspace holds one queue slot per vector (plus padding) whatever the shape
     for n in (1, 63, 64, 65, 4096, 4097, 1 << 22):
@@ -73,6 +74,14 @@ def test_sorted_layout_and_prune_shapes():
     assert rc == _lib.VQ_E_INVALID
     rc = lib.vq_blocks_sort(ctypes.c_void_p(16), 10, 16, ctypes.c_void_p(16), 8, None)
     assert rc == _lib.VQ_E_WORKSPACE and "sorted buffer" in _lib.last_error()
+    # a search is refused a `sorted` argument that is too small, or that vq_blocks_sort never filled
+    # (both checks are host arithmetic and come before any HIP call)
+    ws_bytes = lib.vq_workspace_bytes(64, 16, 100)
+    p16 = ctypes.c_void_p(4096)
+    rc = lib.vq_encode_l1_prepared(p16, p16, 8, 100, 16, p16, 64, p16, None, p16, ws_bytes, None)
+    assert rc == _lib.VQ_E_INVALID and "sorted buffer of 8 bytes" in _lib.last_error()
+    rc = lib.vq_encode_l1_prepared(p16, p16, lib.vq_sorted_bytes(16, 100), 100, 16, p16, 64, p16, None, p16, ws_bytes, None)
+    assert rc == _lib.VQ_E_INVALID and "not filled by vq_blocks_sort" in _lib.last_error()
 
 
 def test_engine_refuses_to_run_without_gpu():

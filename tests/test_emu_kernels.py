@@ -64,15 +64,10 @@ def test_emu_window_sort(eng, N, d):
 
 @pytest.mark.parametrize("N,d", [(700, 16), (8192 + 300, 16), (3000, 4), (2600, 12), (1900, 8)])
 def test_emu_window_sort_lds_variant(eng, N, d):
-    """The LDS-staged sort kernel (opt-in until it has run on hardware) produces a valid sorted copy."""
+    """Rows of 1 .. 4 aligned words take the LDS-staged sort kernel: it produces a valid sorted copy."""
     rng = np.random.default_rng(N * 3 + d)
     blocks = np.clip(rng.integers(0, 200, size=(N, 1)) + rng.integers(0, 56, size=(N, d)), 0, 255).astype(np.uint8)
-    os.environ["VQ_SORT_LDS"] = "1"
-    try:
-        buf = eng.sort_blocks(T(blocks))
-    finally:
-        del os.environ["VQ_SORT_LDS"]
-    _check_sorted(buf, blocks)
+    _check_sorted(eng.sort_blocks(T(blocks)), blocks)
 
 
 @pytest.mark.parametrize("K,d,N", [(40, 16, 1500), (5, 12, 700), (70, 48, 600), (300, 8, 900), (20, 192, 500),
@@ -169,18 +164,12 @@ def test_emu_codebook_class_reproduces_reference_golden(tmp_path):
 
 @pytest.mark.parametrize("K,bh,bw,C,nr,nc", [(256, 4, 4, 1, 16, 64), (17, 2, 2, 3, 5, 8), (33, 8, 8, 3, 3, 4), (9, 3, 3, 1, 4, 5)])
 def test_emu_decode_both_kernels(eng, oracle, K, bh, bw, C, nr, nc):
-    """k_decode_u8 and the block-row variant (opt-in until it has run on hardware) give the same image."""
+    """Word-wide block rows take k_decode_blockrows_u8, the rest the byte-wise k_decode_u8."""
     rng = np.random.default_rng(K + nr)
     cb = rng.random((K, bh * bw * C)) * 300.0 - 20.0
     labels = rng.integers(0, K, size=(nr, nc)).astype(np.int32)
     want = oracle.decode_u8(labels, cb, bh, bw, C)
     assert np.array_equal(eng.decode(T(labels), T(cb), bh, bw, C).numpy(), want)
-    os.environ["VQ_DECODE_BLOCKROWS"] = "1"
-    try:
-        got = eng.decode(T(labels), T(cb), bh, bw, C).numpy()
-    finally:
-        del os.environ["VQ_DECODE_BLOCKROWS"]
-    assert np.array_equal(got, want)
 
 
 def test_emu_prepared_codebook_and_label_accumulation(eng, oracle):
@@ -205,21 +194,16 @@ def test_emu_prepared_codebook_and_label_accumulation(eng, oracle):
 
 @pytest.mark.parametrize("K,d,N", [(100, 48, 1500), (64, 64, 1200), (40, 33, 900)])
 def test_emu_pruned_search_for_wide_rows(eng, oracle, K, d, N):
-    """Rows of 34 .. 64 bytes (RGB 4x4 blocks) through the pruned search: opt-in (VQ_PRUNE_WIDE=1) until it
-    has run on hardware.  Encode and one LBG pass (separate accumulation) against the oracle."""
+    """Rows of 34 .. 64 bytes (RGB 4x4 blocks) through the pruned search (two vectors per lane): encode and
+    one LBG pass (separate accumulation) against the oracle."""
     rng = np.random.default_rng(K + d)
     blocks, cb = _structured(rng, K, d, N)
     want = oracle.lbg_iter(blocks, cb)
     b = T(blocks)
     srt = eng.sort_blocks(b)
-    assert not eng.prune_supported(K, d)
-    os.environ["VQ_PRUNE_WIDE"] = "1"
-    try:
-        assert eng.prune_supported(K, d)
-        got_l, got_d = eng.encode(b, T(cb), want_dist=True, mode=1, sorted=srt)
-        acc, dist, labels = eng.lbg_accum(b, T(cb), want_labels=True, mode=1, sorted=srt)
-    finally:
-        del os.environ["VQ_PRUNE_WIDE"]
+    assert eng.prune_supported(K, d)
+    got_l, got_d = eng.encode(b, T(cb), want_dist=True, mode=1, sorted=srt)
+    acc, dist, labels = eng.lbg_accum(b, T(cb), want_labels=True, mode=1, sorted=srt)
     assert np.array_equal(got_l.numpy(), want["labels"]) and np.array_equal(got_d.numpy(), want["min_dist"])
     a = acc.numpy().astype(np.uint64)
     assert np.array_equal(labels.numpy(), want["labels"])
@@ -229,8 +213,9 @@ def test_emu_pruned_search_for_wide_rows(eng, oracle, K, d, N):
 
 @pytest.mark.parametrize("K,d,N,use_sorted", [(64, 16, 800, True), (200, 12, 500, False), (33, 48, 300, False), (2, 16, 300, False)])
 def test_emu_pruned_fixup(eng, oracle, K, d, N, use_sorted):
-    """The fix-up pass with the element-sum bound (opt-in, VQ_FIXUP_PRUNE=1) on data full of exact ties and
-    near-ties, so that most vectors are queued: labels, distances and cluster sums as the oracle's."""
+    """The fix-up pass with the element-sum bound (the library uses it from K = 512 on; the emulated build
+    exposes that threshold as a variable so that small cases reach the kernel) on data full of exact ties
+    and near-ties, so that most vectors are queued: labels, distances and cluster sums as the oracle's."""
     rng = np.random.default_rng(K * 11 + d)
     base = np.clip(rng.random((max(2, K // 3), 1)) * 255 + rng.normal(0, 15, (max(2, K // 3), d)), 0, 255)
     cb = base[rng.integers(0, len(base), K)] + rng.choice([0.0, 0.001, -0.002, 0.5], size=(K, 1))     # twins and near-twins
@@ -238,12 +223,15 @@ def test_emu_pruned_fixup(eng, oracle, K, d, N, use_sorted):
     want = oracle.lbg_iter(blocks, cb)
     b = T(blocks)
     srt = eng.sort_blocks(b) if use_sorted else None
-    os.environ["VQ_FIXUP_PRUNE"] = "1"
+    import ctypes
+    from emu_engine import emu_lib
+    min_k = ctypes.c_int.in_dll(emu_lib(), "emu_fixup_prune_min_k")
+    saved, min_k.value = min_k.value, 0
     try:
         got_l, got_d = eng.encode(b, T(cb), want_dist=True, mode=1, sorted=srt)
         acc, dist, labels = eng.lbg_accum(b, T(cb), want_labels=True, mode=1, sorted=srt)
     finally:
-        del os.environ["VQ_FIXUP_PRUNE"]
+        min_k.value = saved
     assert np.array_equal(got_l.numpy(), want["labels"]) and np.array_equal(got_d.numpy(), want["min_dist"])
     a = acc.numpy().astype(np.uint64)
     assert np.array_equal(labels.numpy(), want["labels"])

@@ -524,3 +524,80 @@ def test_full_size_encode_decode_properties(eng, oracle):
     _, mind = eng.encode(blocks, cb, want_dist=True)
     assert dist.item() == float(np.add.reduce(mind.cpu().numpy()))
     assert torch.equal(mind, mind_pruned) and torch.equal(acc, acc_p) and dist.item() == dist_p.item()
+
+
+# ---------------------------------------------------------------------------------------------------
+# misuse of the window-sorted copy is reported, not followed
+# ---------------------------------------------------------------------------------------------------
+def test_sorted_buffer_mismatch_is_refused(eng):
+    rng = np.random.default_rng(77)
+    K, d = 64, 16
+    cb = dev(rng.random((K, d)) * 255.0)
+    a = dev(rng.integers(0, 256, size=(20000, d), dtype=np.uint8))
+    b = dev(rng.integers(0, 256, size=(9000, d), dtype=np.uint8))
+    srt_a = eng.sort_blocks(a)
+    good = eng.encode(a, cb, mode=1, sorted=srt_a)
+    assert torch.equal(good, eng.encode(a, cb, mode=1))
+    # a buffer sorted for another vector count: refused on the host
+    with pytest.raises(ValueError, match="sorted buffer"):
+        eng.encode(b, cb, mode=1, sorted=srt_a)
+    # a buffer vq_blocks_sort never filled
+    fresh = torch.zeros_like(srt_a)
+    with pytest.raises(ValueError, match="not filled by vq_blocks_sort"):
+        eng.encode(a, cb, mode=1, sorted=fresh)
+    # contents replaced after the sort (the header no longer says N, d): every label comes back -1 and the
+    # stale origin map is not followed
+    srt_a.zero_()
+    bad = eng.encode(a, cb, mode=1, sorted=srt_a)
+    assert bool((bad == -1).all())
+    # sorting again makes the buffer valid again
+    eng.sort_blocks(a, out=srt_a)
+    assert torch.equal(eng.encode(a, cb, mode=1, sorted=srt_a), good)
+
+
+def test_decompress_rejects_out_of_range_labels(tmp_path):
+    """codebook[labels[r][c]] in the reference: negative labels count from the end, anything else outside
+    [-K, K) raises IndexError (VQ_Full.py:162)."""
+    import json
+    from vector_quantization_amd import Codebook
+    cb = (np.arange(4 * 2 * 2 * 3, dtype=np.float64).reshape(4, 2, 2, 3) * 3.0).tolist()
+    cbp, lp, op = tmp_path / "cb.json", tmp_path / "l.json", tmp_path / "o.png"
+    json.dump(cb, open(cbp, "w"))
+    json.dump([[0, -1, 3], [-4, 2, 1]], open(lp, "w"))
+    arr = Codebook.decompress(str(lp), str(cbp), str(op), device="cuda:0")
+    json.dump([[0, 3, 3], [0, 2, 1]], open(lp, "w"))
+    assert np.array_equal(arr, Codebook.decompress(str(lp), str(cbp), str(op), device="cuda:0"))
+    for bad in (4, -5, 1000000):
+        json.dump([[0, bad, 3], [0, 2, 1]], open(lp, "w"))
+        with pytest.raises(IndexError, match=f"index {bad} is out of bounds for axis 0 with size 4"):
+            Codebook.decompress(str(lp), str(cbp), str(op), device="cuda:0")
+
+
+# ---------------------------------------------------------------------------------------------------
+# RGB 8x8 blocks (d = 192), K = 4096: the reference's own run on team.jpg (N = 19 200)
+# ---------------------------------------------------------------------------------------------------
+def test_rgb_8x8_k4096_training_and_encode_match_reference(tmp_path, capsys):
+    import hashlib
+    from vector_quantization_amd import Codebook
+    g = load_golden("team_8x8_k4096")
+    cb = Codebook.from_array(g["img"], 8, 8, base_name="team", device="cuda:0", output_dir=str(tmp_path))
+    assert cb.blocks.shape == (19200, 192)
+    cb.generate_codebook(4096)
+    out = capsys.readouterr().out
+    assert cb.training.iters_per_stage == list(g["iters_per_stage"])
+    assert cb.training.converged_iter == list(g["converged_iter"])
+    assert np.array_equal(np.array(cb.training.distortions), g["distortions"])
+    assert np.array_equal(cb.codebook, g["codebook"])
+    ref_conv = [l for l in str(g["log"]).splitlines() if l.startswith("Converged")]
+    assert [l for l in out.splitlines() if l.startswith("Converged")] == ref_conv
+    labels = cb.compress()
+    assert np.array_equal(labels, g["labels"])
+    assert np.array_equal(np.fromfile(cb.labels_bin, dtype=np.uint8), g["labels_bin"])
+    assert hashlib.sha256(open(cb.codebook_json, "rb").read()).hexdigest() == str(g["codebook_json_sha256"])
+    assert hashlib.sha256(open(cb.labels_json, "rb").read()).hexdigest() == str(g["labels_json_sha256"])
+    arr = Codebook.decompress(cb.labels_json, cb.codebook_json, cb.reconstructed_path, device="cuda:0")
+    assert hashlib.sha256(arr.tobytes()).hexdigest() == str(g["decoded_sha256"])
+    # the last iteration's per-vector distances (the values VQ_Full.py:89 gathers), exact-mode cross-check
+    eng2 = cb._engine
+    lab_x, mind_x = eng2.encode(cb._blocks_dev, dev(g["codebook"]), want_dist=True, mode=0)
+    assert np.array_equal(lab_x.cpu().numpy().reshape(labels.shape), g["labels"])

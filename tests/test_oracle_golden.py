@@ -165,3 +165,27 @@ def test_split_and_mean_match_numpy(oracle):
         m = labels == k
         want = np.mean(blocks[m], axis=0) if m.any() else cb[k]                                      # VQ_Full.py:81-86
         assert np.array_equal(new[k], want)
+
+
+def test_rgb_8x8_k4096_encode_decode_pack(oracle):
+    """d = 192, K = 4096 (team.jpg, N = 19 200): blocks, labels, decoded pixels and the packed bit stream of
+    the reference's own run.  The full training of this case takes the oracle minutes: VQ_SLOW_TESTS=1."""
+    import hashlib
+    g = load_golden("team_8x8_k4096")
+    blocks = oracle.blocks_u8(g["img"], 8, 8)
+    assert blocks.shape == (19200, 192)
+    labels, mind = oracle.encode_l1(blocks, g["codebook"], want_dist=True)
+    assert np.array_equal(labels.astype(np.int64).reshape(g["labels"].shape), g["labels"])
+    img = oracle.decode_u8(g["labels"], g["codebook"], 8, 8, 3)
+    assert hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == str(g["decoded_sha256"])
+    assert np.array_equal(oracle.pack_labels(g["labels"].reshape(-1), 4096), g["labels_bin"])
+
+
+@pytest.mark.skipif(not __import__("os").environ.get("VQ_SLOW_TESTS"), reason="minutes of CPU: set VQ_SLOW_TESTS=1")
+def test_rgb_8x8_k4096_full_training(oracle):
+    g = load_golden("team_8x8_k4096")
+    blocks = oracle.blocks_u8(g["img"], 8, 8)
+    r = oracle.lbg_train(blocks, 4096, float(g["eps"]), float(g["thr"]), int(g["max_iter"]))
+    assert np.array_equal(r["iters_per_stage"], g["iters_per_stage"])
+    assert np.array_equal(r["distortions"], g["distortions"])
+    assert np.array_equal(r["codebook"], g["codebook"])

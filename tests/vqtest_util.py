@@ -9,6 +9,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 TRAIN_CASES = [
     "luffy_2x2_k16", "man_4x4_k256", "man_2x2_k5", "luffy_4x4_k32", "luffy_8x8_k8",
     "synth_gray_zero_sat_4x4_k256", "synth_gray_250x246_4x4_k64", "man_2x2_k1", "synth_iid_128_4x4_k32",
+    "synth_gray_1024_4x4_k1024",
 ]
 
 

@@ -81,7 +81,7 @@ class Codebook:
         self._blocks_sorted = None
         self._img_padded = None
         self._codebook_dev = None
-        self.codebook = None
+        self._codebook = None
 
         out_dir = output_dir if output_dir is not None else script_dir
         self.base_name = os.path.splitext(os.path.basename(str(self.path)))[0]
@@ -111,6 +111,20 @@ class Codebook:
     def image_to_blocks(self):
         return self.blocks
 
+    @property
+    def codebook(self):
+        """(K, d) float64 codebook on the host, as VQ_Full.py:88 leaves it.  The reference reads this
+        attribute afresh in compress (VQ_Full.py:124), so assigning another codebook must take effect:
+        the setter drops the device copy, and compress re-uploads whenever the host array is no longer
+        the one the device copy was made from (in-place edits included)."""
+        return self._codebook
+
+    @codebook.setter
+    def codebook(self, value):
+        self._codebook = value
+        self._codebook_dev = None
+        self._codebook_dev_src = None
+
     def _sorted_blocks(self):
         """Second device layout of the block matrix (windows sorted by element sum) that lets the
         search skip codewords; built on first use, shared by training and compress."""
@@ -129,8 +143,9 @@ class Codebook:
         res = _lbg.train_lbg(self._engine, self._blocks_dev, k, epsilon, threshold, max_iterations,
                              group=self._group, log=print, iters_per_stage=iters_per_stage,
                              sorted=self._sorted_blocks())
-        self._codebook_dev = res.codebook
         self.codebook = res.codebook.cpu().numpy()
+        self._codebook_dev = res.codebook
+        self._codebook_dev_src = self._codebook.copy()
         self.training = res
 
         final = self.codebook.reshape(-1, self.block_h, self.block_w, self.channels).tolist()
@@ -153,9 +168,15 @@ class Codebook:
     def compress(self):
         if self.codebook is None:
             raise ValueError("No codebook yet.")
-        if self._codebook_dev is None:                       # codebook assigned by the caller
-            self._codebook_dev = torch.from_numpy(np.ascontiguousarray(self.codebook, dtype=np.float64)).to(
-                self._engine.device)
+        host = np.ascontiguousarray(self.codebook, dtype=np.float64)
+        if host.ndim != 2 or host.shape[1] != self._blocks_dev.shape[1]:
+            raise ValueError(f"codebook must be (K, {self._blocks_dev.shape[1]}), got {host.shape}")
+        if (self._codebook_dev is None or self._codebook_dev_src is None
+                or self._codebook_dev_src.shape != host.shape
+                or not np.array_equal(self._codebook_dev_src.view(np.uint64), host.view(np.uint64))):
+            # assigned or edited by the caller since the device copy was made
+            self._codebook_dev = torch.from_numpy(host).to(self._engine.device)
+            self._codebook_dev_src = host.copy()
         labels_dev = self._engine.encode(self._blocks_dev, self._codebook_dev, sorted=self._sorted_blocks())
         self._labels_dev = labels_dev
         labels_grid = labels_dev.cpu().numpy().astype(np.int64).reshape(self.n_rows, self.n_cols)
@@ -182,6 +203,17 @@ class Codebook:
             codebook = np.array(json.load(f))
         n_rows, n_cols = labels.shape
         block_h, block_w, channels = codebook.shape[1], codebook.shape[2], codebook.shape[3]
+        # codebook[labels[r][c]] (VQ_Full.py:162): a negative index counts from the end, anything outside
+        # [-K, K) raises IndexError -- checked here, because the gather kernel does not range-check
+        K = len(codebook)
+        if labels.size and not np.issubdtype(labels.dtype, np.integer):
+            raise IndexError("only integers, slices (`:`), ellipsis (`...`), numpy.newaxis (`None`) and integer or "
+                             "boolean arrays are valid indices")
+        bad = (labels < -K) | (labels >= K)
+        if bad.any():
+            v = int(labels[bad].ravel()[0])
+            raise IndexError(f"index {v} is out of bounds for axis 0 with size {K}")
+        labels = np.where(labels < 0, labels + K, labels)
         eng = engine if engine is not None else _default_engine(device)
         lab_dev = torch.from_numpy(labels.astype(np.int32)).to(eng.device)
         cb_dev = torch.from_numpy(np.ascontiguousarray(codebook, dtype=np.float64).reshape(len(codebook), -1)).to(

@@ -32,11 +32,14 @@
 //
 // No entry point allocates memory; scratch comes in through the workspace argument.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <unordered_map>
 
 #include "vq_hip.h"
 
@@ -67,7 +70,7 @@ int fail(int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(VQ_E_HIP, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
     } while (0)
 
-constexpr int ABI_VERSION = 2;
+constexpr int ABI_VERSION = 3;
 constexpr int WAVE = 64;
 constexpr int64_t NP_CHUNK = 8192;      // numpy's reduction buffer: elements per pairwise-summed chunk
 constexpr int MAX_D_FAST = 192;         // largest vector dimension of the SAD filter kernels
@@ -89,6 +92,14 @@ constexpr int MAX_K = 1 << 20;
 #endif
 #ifndef VQ_GP
 #define VQ_GP 16
+#endif
+// Pruned search for rows of 34 .. 64 bytes (0 = such rows take the LDS-tiled full search).
+#ifndef VQ_PRUNE_WIDE
+#define VQ_PRUNE_WIDE 1
+#endif
+// Smallest codebook for which the fix-up pass uses the element-sum bound (k_fixup_pruned).
+#ifndef VQ_FIXUP_PRUNE_MIN_K
+#define VQ_FIXUP_PRUNE_MIN_K 512
 #endif
 
 // Sorted-codebook position table: entry t = number of codewords whose fixed-point element sum is
@@ -164,6 +175,18 @@ struct PrepHeader {
     uint32_t pad[58];
 };
 static_assert(sizeof(PrepHeader) == 256, "header is one 256-byte slot");
+
+// Header at the end of a window-sorted buffer, written by the sort kernel and verified by the pruned
+// search before it trusts the origin map (a buffer whose contents were replaced since the sort makes
+// the search write label -1 everywhere instead of following stale origins).
+constexpr uint32_t SORTED_MAGIC = 0x56515352u;      // "VQSR"
+struct SortedHeader {
+    uint32_t magic;
+    uint32_t d;
+    unsigned long long N;
+    uint32_t pad[60];
+};
+static_assert(sizeof(SortedHeader) == 256, "header is one 256-byte slot");
 
 // ------------------------------------------------------------------------------------------------
 // device helpers
@@ -586,11 +609,17 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
 // `perm` (position inside the window).  Vectors never leave their window, so everything the search
 // later writes per vector (label, distance) lands within 32 / 64 KB of its neighbours.  The order
 // inside a bucket depends on the order the atomics retire in; nothing computed from the sorted copy
-// depends on it.  VEC16: d == 16 and 16-byte aligned rows (one 16-byte load and store per vector).
-template <bool VEC16>
+// depends on it.  This kernel serves rows of any length and alignment, byte by byte; rows of one to
+// four aligned words take k_window_sort_lds.
 __global__ __launch_bounds__(1024) void k_window_sort(const uint8_t *__restrict__ blocks, int64_t N, int d, int bshift,
-                                                      uint8_t *__restrict__ rows, uint16_t *__restrict__ perm) {
+                                                      uint8_t *__restrict__ rows, uint16_t *__restrict__ perm,
+                                                      SortedHeader *__restrict__ shdr) {
     constexpr int T = 1024;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        shdr->magic = SORTED_MAGIC;
+        shdr->d = (uint32_t)d;
+        shdr->N = (unsigned long long)N;
+    }
     constexpr int PER = SORT_WIN / T;                       // vectors per thread
     __shared__ uint32_t s_cnt[SORT_BUCKETS];
     __shared__ uint32_t s_wsum[T / WAVE];
@@ -598,7 +627,6 @@ __global__ __launch_bounds__(1024) void k_window_sort(const uint8_t *__restrict_
     const int64_t w0 = (int64_t)blockIdx.x * SORT_WIN;
     for (int i = tid; i < SORT_BUCKETS; i += T) s_cnt[i] = 0u;
     __syncthreads();
-    uint4 keep[PER];
     uint32_t bucket[PER], rank[PER];
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
@@ -607,17 +635,8 @@ __global__ __launch_bounds__(1024) void k_window_sort(const uint8_t *__restrict_
         rank[j] = 0;
         if (n < N) {
             uint32_t sum = 0;
-            if (VEC16) {
-                const uint4 v = reinterpret_cast<const uint4 *>(blocks)[n];
-                keep[j] = v;
-                sum = __builtin_amdgcn_sad_u8(v.x, 0u, sum);
-                sum = __builtin_amdgcn_sad_u8(v.y, 0u, sum);
-                sum = __builtin_amdgcn_sad_u8(v.z, 0u, sum);
-                sum = __builtin_amdgcn_sad_u8(v.w, 0u, sum);
-            } else {
-                const uint8_t *row = blocks + (size_t)n * d;
-                for (int e = 0; e < d; ++e) sum += row[e];
-            }
+            const uint8_t *row = blocks + (size_t)n * d;
+            for (int e = 0; e < d; ++e) sum += row[e];
             bucket[j] = sum >> bshift;
             rank[j] = atomicAdd(&s_cnt[bucket[j]], 1u);
         }
@@ -646,13 +665,9 @@ __global__ __launch_bounds__(1024) void k_window_sort(const uint8_t *__restrict_
         const int64_t n = w0 + li;
         if (n < N) {
             const int64_t slot = w0 + (int64_t)(s_cnt[bucket[j]] + rank[j]);
-            if (VEC16) {
-                reinterpret_cast<uint4 *>(rows)[slot] = keep[j];
-            } else {
-                const uint8_t *src = blocks + (size_t)n * d;
-                uint8_t *dst = rows + (size_t)slot * d;
-                for (int e = 0; e < d; ++e) dst[e] = src[e];
-            }
+            const uint8_t *src = blocks + (size_t)n * d;
+            uint8_t *dst = rows + (size_t)slot * d;
+            for (int e = 0; e < d; ++e) dst[e] = src[e];
             perm[slot] = (uint16_t)li;
         }
     }
@@ -664,8 +679,14 @@ __global__ __launch_bounds__(1024) void k_window_sort(const uint8_t *__restrict_
 // Dynamic LDS: [SORT_WIN * DW words of rows][SORT_WIN uint16 origins].
 template <int DW>
 __global__ __launch_bounds__(1024) void k_window_sort_lds(const uint32_t *__restrict__ blocks, int64_t N, int bshift,
-                                                          uint32_t *__restrict__ rows, uint16_t *__restrict__ perm) {
+                                                          uint32_t *__restrict__ rows, uint16_t *__restrict__ perm,
+                                                          SortedHeader *__restrict__ shdr) {
     constexpr int T = 1024;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        shdr->magic = SORTED_MAGIC;
+        shdr->d = (uint32_t)(4 * DW);
+        shdr->N = (unsigned long long)N;
+    }
     constexpr int PER = SORT_WIN / T;                       // vectors per thread
     extern __shared__ __align__(16) uint32_t s_rows[];
     uint16_t *s_perm = reinterpret_cast<uint16_t *>(s_rows + (size_t)SORT_WIN * DW);
@@ -773,6 +794,7 @@ struct AssignArgs {
     const uint8_t *rows;        // N * d bytes: the vectors, each window of SORT_WIN sorted by element sum
     const uint16_t *perm;       // N: position inside its window of the vector now at sorted position i
     const uint32_t *postab;     // sum threshold -> position in the sorted codebook
+    const SortedHeader *shdr;   // what the sorted copy holds (verified before the origin map is trusted)
 };
 
 // Codewords per LDS tile of the LDS_CW variant (about 4 KB of fixed-point rows per tile).
@@ -826,6 +848,20 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
         __syncthreads();
     }
 
+    if (PRUNE) {
+        // (wave-uniform) the sorted copy must be the one made for these N vectors of d bytes; otherwise its
+        // origin map cannot be trusted: every label of this workgroup's tiles becomes -1 and nothing else
+        // is written
+        if (a.shdr->magic != SORTED_MAGIC || a.shdr->N != (unsigned long long)a.N || a.shdr->d != (uint32_t)a.d) {
+            for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+                for (int r = 0; r < R; ++r) {
+                    const int64_t n = tile * (int64_t)(BLOCK * R) + (int64_t)r * BLOCK + tid;
+                    if (n < a.N) a.labels[n] = -1;
+                }
+            }
+            return;
+        }
+    }
     const uint32_t s = a.hdr->shift;
     const uint32_t emax = a.hdr->emax;
     const uint32_t window = emax >= 0x3fffffffu ? 0xffffffffu : 2u * emax;   // ambiguous iff S2 - S1 <= window
@@ -1668,12 +1704,11 @@ __global__ __launch_bounds__(256) void k_cb_to_u8(const double *__restrict__ cb,
         out[i] = cast_u8(cb[i]);
 }
 
-// One thread per G consecutive output bytes of an image row: G = 16 (four 4-byte words gathered
-// from the truncated codebook, one 16-byte store) or 4 when a block row segment is a multiple of 4
-// bytes, else 1.  blockIdx.y strides over image rows, so all index arithmetic is 32-bit.  With
-// LDS_CB each workgroup truncates the fp64 codebook into LDS once (K*d bytes) and gathers from
+// Byte-wise decode for block row segments that are not a whole number of aligned words: one thread per
+// output byte of an image row.  blockIdx.y strides over image rows, so all index arithmetic is 32-bit.
+// With LDS_CB each workgroup truncates the fp64 codebook into LDS once (K*d bytes) and gathers from
 // there; otherwise it gathers from the uint8 copy that k_cb_to_u8 left in global memory.
-template <int G, bool LDS_CB>
+template <bool LDS_CB>
 __global__ __launch_bounds__(256) void k_decode_u8(const int32_t *__restrict__ labels, int nr, int nc,
                                                    const double *__restrict__ cb, const uint8_t *__restrict__ cb8g,
                                                    int K, int bh, int bw, int C, uint8_t *__restrict__ img) {
@@ -1681,7 +1716,6 @@ __global__ __launch_bounds__(256) void k_decode_u8(const int32_t *__restrict__ l
     const uint32_t seg = (uint32_t)(bw * C);
     const uint32_t d = (uint32_t)bh * seg;
     const uint32_t rowbytes = (uint32_t)nc * seg;
-    const uint32_t groups_per_row = rowbytes / G;
     const uint32_t rows = (uint32_t)nr * (uint32_t)bh;
     if (LDS_CB) {
         const uint32_t n = (uint32_t)K * d;
@@ -1693,38 +1727,17 @@ __global__ __launch_bounds__(256) void k_decode_u8(const int32_t *__restrict__ l
         const uint32_t r = y / (uint32_t)bh, i = y - r * (uint32_t)bh;
         const int32_t *lrow = labels + (size_t)r * nc;
         uint8_t *orow = img + (size_t)y * rowbytes;
-        for (uint32_t xg = blockIdx.x * blockDim.x + threadIdx.x; xg < groups_per_row; xg += gridDim.x * blockDim.x) {
-            const uint32_t xb0 = xg * G;
-            if constexpr (G == 1) {
-                uint32_t q = xb0 / seg, rem = xb0 - q * seg;
-                orow[xb0] = cb8[(size_t)lrow[q] * d + i * seg + rem];
-            } else {
-                constexpr int NW = G >= 4 ? G / 4 : 1;
-                uint32_t words[NW];
-                uint32_t q = xb0 / seg, rem = xb0 - q * seg;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    words[w] = *reinterpret_cast<const uint32_t *>(cb8 + (size_t)lrow[q] * d + i * seg + rem);
-                    rem += 4;
-                    if (rem >= seg) {
-                        rem = 0;
-                        ++q;
-                    }
-                }
-                if (G == 16) {
-                    uint4 out = make_uint4(words[0], words[1 % NW], words[2 % NW], words[3 % NW]);
-                    *reinterpret_cast<uint4 *>(orow + xb0) = out;
-                } else {
-                    *reinterpret_cast<uint32_t *>(orow + xb0) = words[0];
-                }
-            }
+        for (uint32_t xb = blockIdx.x * blockDim.x + threadIdx.x; xb < rowbytes; xb += gridDim.x * blockDim.x) {
+            const uint32_t q = xb / seg, rem = xb - q * seg;
+            orow[xb] = cb8[(size_t)lrow[q] * d + i * seg + rem];
         }
     }
 }
 
-// The same decode with blockIdx.y striding over BLOCK rows: a thread fetches the labels its G output
-// bytes need once and writes all bh pixel rows of that block row (k_decode_u8 fetches them again for
-// every pixel row: 4 x the label traffic at 4x4 blocks).  G = 16 or 4.
+// Decode for block row segments that are whole aligned words.  One thread per G consecutive output bytes
+// of an image row (G = 16: four words gathered from the truncated codebook, one 16-byte store; G = 4: one
+// word); blockIdx.y strides over BLOCK rows: a thread fetches the labels its G bytes need once and writes
+// all bh pixel rows of that block row, so every label is read once.
 template <int G, bool LDS_CB>
 __global__ __launch_bounds__(256) void k_decode_blockrows_u8(const int32_t *__restrict__ labels, int nr, int nc,
                                                              const double *__restrict__ cb,
@@ -1894,14 +1907,31 @@ struct DeviceInfo {
     size_t lds_per_block;
 };
 
+// Properties of the current device.  They never change while the process lives, so each device is
+// queried once; the table is written under a mutex and only ever read afterwards.
+constexpr int MAX_DEVICES = 64;
+std::mutex g_di_mutex;
+std::atomic<int> g_di_ready[MAX_DEVICES];
+DeviceInfo g_di[MAX_DEVICES];
+
 int device_info(DeviceInfo &di) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
+    const bool cached = dev >= 0 && dev < MAX_DEVICES;
+    if (cached && g_di_ready[dev].load(std::memory_order_acquire)) {
+        di = g_di[dev];
+        return VQ_OK;
+    }
     int cus = 0, lds = 0;
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     HIP_TRY(hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
     di.cus = cus;
     di.lds_per_block = (size_t)lds;
+    if (cached) {
+        std::lock_guard<std::mutex> lock(g_di_mutex);
+        g_di[dev] = di;
+        g_di_ready[dev].store(1, std::memory_order_release);
+    }
     return VQ_OK;
 }
 
@@ -1961,10 +1991,12 @@ int run_prepare(const double *cb, int K, int d, void *ws, hipStream_t st) {
     return VQ_OK;
 }
 
-// Layout of the buffer vq_blocks_sort fills: the sorted rows, then the window-local origins.
+// Layout of the buffer vq_blocks_sort fills: the sorted rows, the window-local origins, then a header
+// that says what the buffer holds.
 struct SortedLayout {
     size_t rows;       // N * d bytes
     size_t perm;       // N uint16
+    size_t hdr;        // SortedHeader
     size_t total;
 };
 
@@ -1972,8 +2004,39 @@ SortedLayout sorted_layout(int d, int64_t N) {
     SortedLayout L;
     L.rows = 0;
     L.perm = align_up((size_t)N * d, 256);
-    L.total = L.perm + align_up((size_t)N * 2, 256);
+    L.hdr = L.perm + align_up((size_t)N * 2, 256);
+    L.total = L.hdr + 256;
     return L;
+}
+
+// Host-side record of the buffers vq_blocks_sort has filled (keyed by device address): the search
+// refuses a `sorted` argument that was never filled, or was filled for another N or d, instead of
+// reading past its end.  Guarded by a mutex; an entry is replaced when the same address is sorted again.
+struct SortedInfo {
+    int64_t N;
+    int d;
+    size_t bytes;
+};
+std::mutex g_sorted_mutex;
+std::unordered_map<uintptr_t, SortedInfo> g_sorted_known;
+
+void sorted_register(const void *sorted, int64_t N, int d, size_t bytes) {
+    std::lock_guard<std::mutex> lock(g_sorted_mutex);
+    g_sorted_known[reinterpret_cast<uintptr_t>(sorted)] = SortedInfo{N, d, bytes};
+}
+
+int sorted_check(const void *sorted, size_t sorted_bytes, int64_t N, int d) {
+    const size_t need = sorted_layout(d, N).total;
+    if (sorted_bytes < need)
+        return fail(VQ_E_INVALID, "sorted buffer of %zu bytes given, N=%lld d=%d needs %zu", sorted_bytes, (long long)N, d, need);
+    std::lock_guard<std::mutex> lock(g_sorted_mutex);
+    auto it = g_sorted_known.find(reinterpret_cast<uintptr_t>(sorted));
+    if (it == g_sorted_known.end())
+        return fail(VQ_E_INVALID, "sorted buffer %p was not filled by vq_blocks_sort", sorted);
+    if (it->second.N != N || it->second.d != d)
+        return fail(VQ_E_INVALID, "sorted buffer %p holds N=%lld d=%d, the call has N=%lld d=%d", sorted,
+                    (long long)it->second.N, it->second.d, (long long)N, d);
+    return VQ_OK;
 }
 
 // The pruned search serves the shapes of the scalar-load kernels, from the codebook size on at
@@ -1983,10 +2046,8 @@ bool prune_supported(int K, int d) {
     if (dp2 <= 0 || K < 32 || K > PREP_SORT_CAP) return false;
     if (!use_lds_codewords(K, dp2)) return true;
     // Rows of 34 .. 64 bytes (RGB 4x4 blocks are 48) whose fixed-point codebook still fits the scalar
-    // cache budget: served by the same kernel, but not run on hardware yet -- opt-in (VQ_PRUNE_WIDE=1)
-    // until its parity tests have passed on a GPU.
-    const char *opt = getenv("VQ_PRUNE_WIDE");
-    return opt && opt[0] == '1' && dp2 <= 32 && (size_t)K * dp2 * 4 <= 32 * 1024;
+    // cache budget are served by the same kernel with two vectors per lane.
+    return VQ_PRUNE_WIDE != 0 && dp2 <= 32 && (size_t)K * dp2 * 4 <= 32 * 1024;
 }
 
 // FAST mode on a prepared workspace: the filter kernel, then the fp64 fix-up of the vectors it
@@ -2003,9 +2064,14 @@ bool fused_acc_supported(const void *sorted, int K, int d) {
 }
 
 // sums / counts non-null (only with fused_acc_supported): cluster sums are accumulated too.
-int run_fast(const uint8_t *blocks, const void *sorted, int64_t N, int d, const double *cb, int K, int32_t *labels,
-             double *min_dist, unsigned long long *sums, unsigned long long *counts, void *ws, hipStream_t st) {
+int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d, const double *cb, int K,
+             int32_t *labels, double *min_dist, unsigned long long *sums, unsigned long long *counts, void *ws,
+             hipStream_t st) {
     const int dp2 = dp2_bucket(d);
+    if (sorted != nullptr && prune_supported(K, d)) {          // before any work is enqueued
+        int src = sorted_check(sorted, sorted_bytes, N, d);
+        if (src) return src;
+    }
     WsLayout L = ws_layout(K, d, 0);
     char *w = static_cast<char *>(ws);
     PrepHeader *hdr = reinterpret_cast<PrepHeader *>(w + L.header);
@@ -2050,13 +2116,14 @@ int run_fast(const uint8_t *blocks, const void *sorted, int64_t N, int d, const 
     a.ntiles = ntiles;
     a.vec4 = ((d & 3) == 0) && ((reinterpret_cast<uintptr_t>(blocks) & 3) == 0);
     if (d == 16 && (reinterpret_cast<uintptr_t>(blocks) & 15) == 0) a.vec4 = 2;     // whole 16-byte rows
-    a.rows = nullptr; a.perm = nullptr;
+    a.rows = nullptr; a.perm = nullptr; a.shdr = nullptr;
     a.postab = reinterpret_cast<const uint32_t *>(w + L.postab);
     if (prune) {
         SortedLayout SL = sorted_layout(d, N);
         const char *sp = static_cast<const char *>(sorted);
         a.rows = reinterpret_cast<const uint8_t *>(sp + SL.rows);
         a.perm = reinterpret_cast<const uint16_t *>(sp + SL.perm);
+        a.shdr = reinterpret_cast<const SortedHeader *>(sp + SL.hdr);
         a.vec4 = ((d & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.rows) & 3) == 0);
         if (d == 16 && (reinterpret_cast<uintptr_t>(a.rows) & 15) == 0) a.vec4 = 2;
         if (SORT_WIN % tile != 0) return fail(VQ_E_HIP, "internal: sort window %d is not a multiple of the tile %lld", SORT_WIN, (long long)tile);
@@ -2080,10 +2147,9 @@ int run_fast(const uint8_t *blocks, const void *sorted, int64_t N, int d, const 
     // fix-up: a fixed grid strides over the sub-queues (their lengths are only known on the device);
     // small codebooks are staged in LDS, one 1024-thread workgroup per CU
     const size_t cb_bytes = (size_t)K * d * sizeof(double);
-    // The pruned fix-up has not been run on hardware yet: opt-in (VQ_FIXUP_PRUNE=1) until its parity tests
-    // have passed on a GPU.  It needs the sorted codebook (K <= PREP_SORT_CAP).
-    const char *fopt = getenv("VQ_FIXUP_PRUNE");
-    if (fopt && fopt[0] == '1' && K <= PREP_SORT_CAP) {
+    // Larger codebooks: the fix-up applies the element-sum bound too (needs the sorted codebook); small
+    // ones are cheaper to scan whole with four queue items in flight per wave.
+    if (K >= VQ_FIXUP_PRUNE_MIN_K && K <= PREP_SORT_CAP) {
         const uint32_t *postab = reinterpret_cast<const uint32_t *>(w + L.postab);
         if (cb_bytes <= 64 * 1024) {
             if (cb_bytes > 48 * 1024)
@@ -2253,7 +2319,7 @@ int vq_encode_l1(const uint8_t *blocks, int64_t N, int d, const double *cb, int 
         if (rc) return rc;
         rc = run_prepare(cb, K, d, ws, st);
         if (rc) return rc;
-        return run_fast(blocks, nullptr, N, d, cb, K, labels, min_dist, nullptr, nullptr, ws, st);
+        return run_fast(blocks, nullptr, 0, N, d, cb, K, labels, min_dist, nullptr, nullptr, ws, st);
     }
     int grid = grid_for(N, 256, 16384);
     hipLaunchKernelGGL(k_assign_exact, dim3(grid), dim3(256), 0, st, blocks, N, d, cb, K, labels, min_dist);
@@ -2272,7 +2338,7 @@ int vq_codebook_prepare(const double *cb, int K, int d, void *ws, size_t ws_byte
 }
 
 size_t vq_sorted_bytes(int d, int64_t N) {
-    if (d <= 0 || N < 0) return 0;
+    if (d <= 0 || N <= 0) return 0;
     return sorted_layout(d, N).total;
 }
 
@@ -2291,6 +2357,7 @@ int vq_blocks_sort(const uint8_t *blocks, int64_t N, int d, void *sorted, size_t
     char *sp = static_cast<char *>(sorted);
     uint8_t *rows = reinterpret_cast<uint8_t *>(sp + SL.rows);
     uint16_t *perm = reinterpret_cast<uint16_t *>(sp + SL.perm);
+    SortedHeader *shdr = reinterpret_cast<SortedHeader *>(sp + SL.hdr);
     int bshift = 0;                                        // element sums 0 .. 255 * d into SORT_BUCKETS buckets
     while (((255u * (uint32_t)d) >> bshift) >= (uint32_t)SORT_BUCKETS) ++bshift;
     const int grid = (int)((N + SORT_WIN - 1) / SORT_WIN);
@@ -2299,10 +2366,8 @@ int vq_blocks_sort(const uint8_t *blocks, int64_t N, int d, void *sorted, size_t
     int rc = device_info(di);
     if (rc) return rc;
     const size_t lds_need = (size_t)SORT_WIN * d + (size_t)SORT_WIN * 2 + (SORT_BUCKETS + 16) * 4 + 256;
-    // The LDS-staged variant has not been run on hardware yet: it is opt-in (VQ_SORT_LDS=1 in the
-    // environment) until its parity tests have passed on a GPU.
-    const char *opt = getenv("VQ_SORT_LDS");
-    const bool words = opt && opt[0] == '1' && (d % 4 == 0) && d <= 16 && (bp & 3) == 0 && (d != 16 || (bp & 15) == 0) &&
+    // rows of 1 .. 4 aligned words: the window is staged in LDS and leaves in order (coalesced stores)
+    const bool words = (d % 4 == 0) && d <= 16 && (bp & 3) == 0 && (d != 16 || (bp & 15) == 0) &&
                        (d != 8 || (bp & 7) == 0) && lds_need <= di.lds_per_block;
     if (words) {
         // rows staged in LDS, coalesced global traffic
@@ -2315,7 +2380,7 @@ int vq_blocks_sort(const uint8_t *blocks, int64_t N, int d, void *sorted, size_t
         if (lds > 48 * 1024)                                                                                        \
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                       \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, st, b32, N, bshift, r32, perm);                       \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, st, b32, N, bshift, r32, perm, shdr);                       \
     } while (0)
         switch (d / 4) {
             case 1: VQ_LAUNCH_SORT(1); break;
@@ -2324,17 +2389,17 @@ int vq_blocks_sort(const uint8_t *blocks, int64_t N, int d, void *sorted, size_t
             default: VQ_LAUNCH_SORT(4); break;
         }
 #undef VQ_LAUNCH_SORT
-    } else if (d == 16 && (bp & 15) == 0) {
-        hipLaunchKernelGGL(k_window_sort<true>, dim3(grid), dim3(1024), 0, st, blocks, N, d, bshift, rows, perm);
     } else {
-        hipLaunchKernelGGL(k_window_sort<false>, dim3(grid), dim3(1024), 0, st, blocks, N, d, bshift, rows, perm);
+        hipLaunchKernelGGL(k_window_sort, dim3(grid), dim3(1024), 0, st, blocks, N, d, bshift, rows, perm, shdr);
     }
     LAUNCH_CHECK("k_window_sort");
+    sorted_register(sorted, N, d, sorted_bytes);
     return VQ_OK;
 }
 
-int vq_encode_l1_prepared(const uint8_t *blocks, const void *sorted, int64_t N, int d, const double *cb, int K,
-                          int32_t *labels, double *min_dist, void *ws, size_t ws_bytes, void *stream) {
+int vq_encode_l1_prepared(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d,
+                          const double *cb, int K, int32_t *labels, double *min_dist, void *ws, size_t ws_bytes,
+                          void *stream) {
     int rc = check_common(blocks, N, d, cb, K);
     if (rc) return rc;
     if (!fast_supported(d)) return fail(VQ_E_UNSUPPORTED, "d=%d is beyond the prepared (fast) kernels", d);
@@ -2343,7 +2408,8 @@ int vq_encode_l1_prepared(const uint8_t *blocks, const void *sorted, int64_t N, 
     if (rc) return rc;
     if (N == 0) return VQ_OK;
     if (!labels) return fail(VQ_E_INVALID, "null labels pointer");
-    return run_fast(blocks, sorted, N, d, cb, K, labels, min_dist, nullptr, nullptr, ws, static_cast<hipStream_t>(stream));
+    return run_fast(blocks, sorted, sorted_bytes, N, d, cb, K, labels, min_dist, nullptr, nullptr, ws,
+                    static_cast<hipStream_t>(stream));
 }
 
 int vq_accum_labels(const uint8_t *blocks, int64_t N, int d, const int32_t *labels, int K, uint64_t *sums,
@@ -2361,9 +2427,9 @@ int vq_numpy_sum_f64(const double *v, int64_t N, double *out, double *chunk_sums
     return run_numpy_sum(v, N, chunk_sums, out, static_cast<hipStream_t>(stream));
 }
 
-int vq_lbg_accum(const uint8_t *blocks, const void *sorted, int64_t N, int d, const double *cb, int K, uint64_t *sums,
-                 uint64_t *counts, int32_t *labels, double *min_dist, double *dist_sum, double *chunk_sums, int mode,
-                 void *ws, size_t ws_bytes, void *stream) {
+int vq_lbg_accum(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d, const double *cb,
+                 int K, uint64_t *sums, uint64_t *counts, int32_t *labels, double *min_dist, double *dist_sum,
+                 double *chunk_sums, int mode, void *ws, size_t ws_bytes, void *stream) {
     int rc = check_common(blocks, N, d, cb, K);
     if (rc) return rc;
     if (!sums || !counts || !dist_sum) return fail(VQ_E_INVALID, "null sums, counts or dist_sum pointer");
@@ -2385,11 +2451,11 @@ int vq_lbg_accum(const uint8_t *blocks, const void *sorted, int64_t N, int d, co
             rc = run_prepare(cb, K, d, ws, st);
             if (rc) return rc;
             if (fused_acc_supported(sorted, K, d)) {
-                rc = run_fast(blocks, sorted, N, d, cb, K, labels, min_dist, s64, c64, ws, st);
+                rc = run_fast(blocks, sorted, sorted_bytes, N, d, cb, K, labels, min_dist, s64, c64, ws, st);
                 if (rc) return rc;
             } else {
-                rc = run_fast(blocks, sorted, N, d, cb, K, labels, dist_in_accum ? nullptr : min_dist, nullptr, nullptr,
-                              ws, st);
+                rc = run_fast(blocks, sorted, sorted_bytes, N, d, cb, K, labels, dist_in_accum ? nullptr : min_dist,
+                              nullptr, nullptr, ws, st);
                 if (rc) return rc;
                 rc = run_accum(blocks, N, d, labels, cb, K, s64, c64, dist_in_accum ? min_dist : nullptr, st);
                 if (rc) return rc;
@@ -2465,10 +2531,8 @@ int vq_decode_u8(const int32_t *labels, int nr, int nc, const double *cb, int K,
     if (gy64 > (int64_t)nr * bh) gy64 = (int64_t)nr * bh;
     if (gy64 > 65535) gy64 = 65535;
     dim3 grid(gx, (unsigned)gy64);
-    // The block-row variant has not been run on hardware yet: opt-in (VQ_DECODE_BLOCKROWS=1) until its
-    // parity tests have passed on a GPU.
-    const char *opt = getenv("VQ_DECODE_BLOCKROWS");
-    if (opt && opt[0] == '1' && G != 1) {
+    // word-wide groups: one thread writes all bh pixel rows of its block row (labels fetched once)
+    if (G != 1) {
         int64_t gyb = ((int64_t)di.cus * 8 + gx - 1) / gx;
         if (gyb > nr) gyb = nr;
         if (gyb > 65535) gyb = 65535;
@@ -2492,23 +2556,14 @@ int vq_decode_u8(const int32_t *labels, int nr, int nc, const double *cb, int K,
         LAUNCH_CHECK("k_decode_blockrows_u8");
         return VQ_OK;
     }
-#define VQ_LAUNCH_DECODE(GG)                                                                                        \
-    do {                                                                                                            \
-        if (lds_cb) {                                                                                               \
-            if (lds > 48 * 1024)                                                                                    \
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_decode_u8<GG, true>),                  \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
-            hipLaunchKernelGGL((k_decode_u8<GG, true>), grid, dim3(256), lds, st, labels, nr, nc, cb, cb8, K, bh, bw, C, \
-                               img);                                                                                \
-        } else {                                                                                                    \
-            hipLaunchKernelGGL((k_decode_u8<GG, false>), grid, dim3(256), 0, st, labels, nr, nc, cb, cb8, K, bh, bw, C,  \
-                               img);                                                                                \
-        }                                                                                                           \
-    } while (0)
-    if (G == 16) VQ_LAUNCH_DECODE(16);
-    else if (G == 4) VQ_LAUNCH_DECODE(4);
-    else VQ_LAUNCH_DECODE(1);
-#undef VQ_LAUNCH_DECODE
+    if (lds_cb) {
+        if (lds > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_decode_u8<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_decode_u8<true>), grid, dim3(256), lds, st, labels, nr, nc, cb, cb8, K, bh, bw, C, img);
+    } else {
+        hipLaunchKernelGGL((k_decode_u8<false>), grid, dim3(256), 0, st, labels, nr, nc, cb, cb8, K, bh, bw, C, img);
+    }
     LAUNCH_CHECK("k_decode_u8");
     return VQ_OK;
 }

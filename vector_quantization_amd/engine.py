@@ -16,6 +16,10 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+def _nbytes(t):
+    return t.numel() * t.element_size() if t is not None else 0
+
+
 class HipEngine:
     """Launches the HIP kernels on one device.  Not thread-safe per instance (it caches its
     workspace); use one engine per host thread, or one per GPU in a multi-process job."""
@@ -111,7 +115,7 @@ class HipEngine:
             with torch.cuda.device(self.device):
                 check(lib.vq_codebook_prepare(_ptr(cb), K, d, _ptr(ws), ws.numel(), self._stream()),
                       "vq_codebook_prepare")
-                check(lib.vq_encode_l1_prepared(_ptr(blocks), _ptr(sorted), N, d, _ptr(cb), K, _ptr(labels), _ptr(mind),
+                check(lib.vq_encode_l1_prepared(_ptr(blocks), _ptr(sorted), _nbytes(sorted), N, d, _ptr(cb), K, _ptr(labels), _ptr(mind),
                                                 _ptr(ws), ws.numel(), self._stream()), "vq_encode_l1_prepared")
             return (labels, mind) if want_dist else labels
         with torch.cuda.device(self.device):
@@ -140,7 +144,7 @@ class HipEngine:
             labels = torch.empty(N, dtype=torch.int32, device=self.device)
         mind = torch.empty(N, dtype=torch.float64, device=self.device) if want_dist else None
         with torch.cuda.device(self.device):
-            check(lib.vq_encode_l1_prepared(_ptr(blocks), _ptr(sorted), N, d, _ptr(cb), K, _ptr(labels), _ptr(mind),
+            check(lib.vq_encode_l1_prepared(_ptr(blocks), _ptr(sorted), _nbytes(sorted), N, d, _ptr(cb), K, _ptr(labels), _ptr(mind),
                                             _ptr(ws), ws.numel(), self._stream()), "vq_encode_l1_prepared")
         return (labels, mind) if want_dist else labels
 
@@ -163,7 +167,7 @@ class HipEngine:
         ws = self._workspace(K, d, N)
         sums, counts = acc[: K * d], acc[K * d:]
         with torch.cuda.device(self.device):
-            check(lib.vq_lbg_accum(_ptr(blocks), _ptr(sorted), N, d, _ptr(cb), K, _ptr(sums), _ptr(counts), _ptr(labels),
+            check(lib.vq_lbg_accum(_ptr(blocks), _ptr(sorted), _nbytes(sorted), N, d, _ptr(cb), K, _ptr(sums), _ptr(counts), _ptr(labels),
                                    _ptr(self._dist_scratch), _ptr(dist), _ptr(chunks),
                                    self.mode if mode is None else mode, _ptr(ws), ws.numel(), self._stream()),
                   "vq_lbg_accum")
