@@ -11,8 +11,8 @@
  *   - Return value: 0 on success, a negative VQ_E_* code on failure; vq_last_error()
  *     returns a thread-local message for the last failure on the calling thread.
  *   - The library may be called from any host thread.  The only state it keeps between calls are
- *     two mutex-guarded tables: device properties (queried once per device) and the buffers
- *     vq_blocks_sort has filled (address -> N, d).
+ *     three mutex-guarded tables: device properties (queried once per device), the buffers
+ *     vq_blocks_sort has filled (address -> N, d), and the per-device address of the static scratch.
  *   - Block vectors are rows of an (N, d) uint8 matrix, d = block_h * block_w * C, element
  *     order (row-in-block, col-in-block, channel), vectors in row-major block-grid order.
  *     Codebooks are (K, d) IEEE doubles, row-major.
@@ -41,6 +41,9 @@ extern "C" {
 
 #define VQ_PAD_EDGE 0   /* replicate last row / column (VQ_Full.py:28-33) */
 #define VQ_PAD_ZERO 1   /* constant 0 (old/CodeBook_VQ.py:26) */
+
+/* Bytes of the static device array behind vq_encode_l1_static (one copy per GPU). */
+#define VQ_STATIC_SCRATCH_BYTES (8u << 20)
 
 /* ABI version of this header; bumped on any signature change. */
 int vq_abi_version(void);
@@ -71,6 +74,18 @@ int vq_colsum_u8(const uint8_t *blocks, int64_t N, int d, uint64_t *sums, void *
  * gathers). */
 int vq_encode_l1(const uint8_t *blocks, int64_t N, int d, const double *cb, int K,
                  int32_t *labels, double *min_dist, int mode, void *ws, size_t ws_bytes, void *stream);
+
+/* vq_encode_l1 for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments
+ * and results as vq_encode_l1 (VQ_Full.py:124-125), but the scratch is a static device array of
+ * VQ_STATIC_SCRATCH_BYTES (8 MiB) inside the library instead of a caller-owned workspace, and the
+ * call allocates nothing.  A (K, d, N) whose vq_workspace_bytes exceeds that size is refused with
+ * VQ_E_UNSUPPORTED (at K = 256, d = 16 about 1.7 million vectors per call fit).  Every call on a GPU
+ * shares that GPU's array: calls that overlap in time on one GPU (different streams or threads)
+ * race on it and must be serialised by the caller. */
+size_t vq_static_scratch_bytes(void);
+int vq_encode_l1_static(const uint8_t *blocks, int64_t N, int d, const double *cb, int K,
+                        int32_t *labels, double *min_dist, int mode, void *stream);
 
 /* Window-sorted copy of the block vectors, the input of the pruned search.  No counterpart in the
  * reference: it is a second layout of self.blocks (VQ_Full.py:51-57), built once per image and

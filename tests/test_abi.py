@@ -84,6 +84,18 @@ def test_sorted_layout_and_prune_shapes():
     assert rc == _lib.VQ_E_INVALID and "not filled by vq_blocks_sort" in _lib.last_error()
 
 
+def test_static_scratch_entry_validates_before_any_gpu_work():
+    from vector_quantization_amd import _lib
+    lib = _lib.lib
+    assert lib.vq_static_scratch_bytes() == 8 << 20
+    p16 = ctypes.c_void_p(4096)
+    # a shape whose workspace exceeds the static array is refused with a message that names the limit
+    rc = lib.vq_encode_l1_static(p16, 1 << 23, 16, p16, 256, p16, None, 1, None)
+    assert rc == _lib.VQ_E_UNSUPPORTED and "static array holds 8388608" in _lib.last_error()
+    rc = lib.vq_encode_l1_static(None, 10, 16, None, 4, None, None, 1, None)
+    assert rc == _lib.VQ_E_INVALID
+
+
 def test_engine_refuses_to_run_without_gpu():
     import pytest
     import torch

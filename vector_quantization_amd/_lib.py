@@ -36,6 +36,8 @@ SIGNATURES = {
     "vq_blocks_u8": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "vq_colsum_u8": (_i, [_vp, _i64, _i, _vp, _vp]),
     "vq_encode_l1": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp]),
+    "vq_static_scratch_bytes": (_sz, []),
+    "vq_encode_l1_static": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp, _i, _vp]),
     "vq_codebook_prepare": (_i, [_vp, _i, _i, _vp, _sz, _vp]),
     "vq_sorted_bytes": (_sz, [_i, _i64]),
     "vq_prune_supported": (_i, [_i, _i]),

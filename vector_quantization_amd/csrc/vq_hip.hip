@@ -43,6 +43,12 @@
 
 #include "vq_hip.h"
 
+// Scratch of vq_encode_l1_static, the entry point for callers that cannot allocate device memory: it
+// takes the place of the caller's workspace.  Every GPU the library runs on holds its own copy of the
+// array, at its own address, until the process ends; host code reaches it only through the address
+// that hipGetSymbolAddress returns for the current device (static_scratch below), never by this name.
+static __device__ __align__(256) unsigned char scratch[VQ_STATIC_SCRATCH_BYTES];
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -1935,6 +1941,30 @@ int device_info(DeviceInfo &di) {
     return VQ_OK;
 }
 
+// Device address of `scratch` on the current device, looked up once per device (with that device
+// current) and kept for the life of the process.
+std::mutex g_scratch_mutex;
+std::atomic<int> g_scratch_ready[MAX_DEVICES];
+void *g_scratch_ptr[MAX_DEVICES];
+
+int static_scratch(void **out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEVICES) return fail(VQ_E_UNSUPPORTED, "device %d is beyond the %d this library tracks", dev, MAX_DEVICES);
+    if (!g_scratch_ready[dev].load(std::memory_order_acquire)) {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ready[dev].load(std::memory_order_relaxed)) {
+            void *ptr = nullptr;
+            HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+            if (!ptr) return fail(VQ_E_HIP, "hipGetSymbolAddress returned a null address for the static scratch");
+            g_scratch_ptr[dev] = ptr;
+            g_scratch_ready[dev].store(1, std::memory_order_release);
+        }
+    }
+    *out = g_scratch_ptr[dev];
+    return VQ_OK;
+}
+
 // Key layout of the filter.  Packed keys hold (S << kbits) + index in 31 bits, so the SAD sum S of
 // 2*dp2 terms, each at most clim, must stay below 2^(31 - kbits); clim is the fixed-point limit the
 // prepare kernel scales codebook and pixels into.  Packed is used when that still leaves at least
@@ -2321,6 +2351,38 @@ int vq_encode_l1(const uint8_t *blocks, int64_t N, int d, const double *cb, int 
         if (rc) return rc;
         return run_fast(blocks, nullptr, 0, N, d, cb, K, labels, min_dist, nullptr, nullptr, ws, st);
     }
+    int grid = grid_for(N, 256, 16384);
+    hipLaunchKernelGGL(k_assign_exact, dim3(grid), dim3(256), 0, st, blocks, N, d, cb, K, labels, min_dist);
+    LAUNCH_CHECK("k_assign_exact");
+    return VQ_OK;
+}
+
+size_t vq_static_scratch_bytes(void) { return (size_t)VQ_STATIC_SCRATCH_BYTES; }
+
+int vq_encode_l1_static(const uint8_t *blocks, int64_t N, int d, const double *cb, int K, int32_t *labels,
+                        double *min_dist, int mode, void *stream) {
+    int rc = check_common(blocks, N, d, cb, K);
+    if (rc) return rc;
+    if (mode != VQ_MODE_EXACT && mode != VQ_MODE_FAST) return fail(VQ_E_INVALID, "unknown mode %d", mode);
+    if (N == 0) return VQ_OK;
+    if (!labels) return fail(VQ_E_INVALID, "null labels pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (mode == VQ_MODE_FAST && fast_supported(d)) {
+        if (N > 0xfffffff0LL) return fail(VQ_E_UNSUPPORTED, "N=%lld exceeds 2^32 per call", (long long)N);
+        const size_t need = ws_layout(K, d, N).total;
+        if (need > (size_t)VQ_STATIC_SCRATCH_BYTES)
+            return fail(VQ_E_UNSUPPORTED,
+                        "K=%d d=%d N=%lld needs %zu bytes of scratch, the static array holds %zu: use vq_encode_l1 "
+                        "with a caller-owned workspace, or split the vectors into smaller calls",
+                        K, d, (long long)N, need, (size_t)VQ_STATIC_SCRATCH_BYTES);
+        void *ws = nullptr;
+        rc = static_scratch(&ws);
+        if (rc) return rc;
+        rc = run_prepare(cb, K, d, ws, st);
+        if (rc) return rc;
+        return run_fast(blocks, nullptr, 0, N, d, cb, K, labels, min_dist, nullptr, nullptr, ws, st);
+    }
+    // the all-fp64 search keeps everything in registers: no scratch at all
     int grid = grid_for(N, 256, 16384);
     hipLaunchKernelGGL(k_assign_exact, dim3(grid), dim3(256), 0, st, blocks, N, d, cb, K, labels, min_dist);
     LAUNCH_CHECK("k_assign_exact");
