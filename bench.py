@@ -1,25 +1,33 @@
 #!/usr/bin/env python3
 """Benchmark of the VQ hot path on MI355X.
 
-Workload (the headline configuration): one synthetic 8192 x 8192 grayscale image per GPU, 4x4 blocks
-(N = 4 194 304 block vectors of dim 16), K = 256 codebook trained by LBG on a 2048 x 2048 crop.
-One step = encode every block vector (nearest codeword, exact labels) + decode the labels back
-to an image, inputs resident in HBM.  `value` = block vectors through that step per second,
-whole job.  Extra keys report the encode kernel alone, decode alone, and LBG iterations/s
-(fused assign + accumulate, all-reduce of sums/counts when N > 1, centroid update).
+Workload (the headline configuration, BASELINE configs[1]): one synthetic 8192 x 8192 grayscale image
+per GPU, 4x4 blocks (N = 4 194 304 block vectors of dim 16), K = 256 codebook trained by LBG on a
+2048 x 2048 crop.  One step starts from the IMAGE resident in HBM: image -> window-sorted block vectors
+(padding + block extraction + sort, one pass), codebook preparation, pruned nearest-codeword search,
+fp64 fix-up of near-ties (exact labels), decode of the labels back to an image.  `value` = block vectors
+through that step per second, whole job.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+Extra keys: the dominant kernel's roofline (executed SAD work against the v_sad_u16 issue ceiling, never
+above 1; the pruning gain is a separate key), the HBM-bound kernels against the HBM roofline, LBG
+iterations/s (fused assign + accumulate, exchange of sums/counts when N > 1, centroid update), a full
+LBG training at the size of configs[2], other shapes (iid worst case, K = 1024, RGB d = 48, d = 192 with
+K = 4096), and the reference's CPU arithmetic timed on this box's host cores (1 core and P processes).
+
+    python bench.py --gpus 1 --steps 200 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -27,55 +35,162 @@ sys.path.insert(0, ROOT)
 H = W = 8192
 BH = BW = 4
 K_CODEBOOK = 256
-PEAK_VALU_TOPS = 78.6       # MI355X fp32 vector peak 157.3 TFLOP/s counts FMA as 2; non-FMA ops/s = half
+# v_sad_u16 issues once per 4 cycles per SIMD for a 64-lane wave and retires two |x - c| accumulations per
+# lane (= 4 algorithmic ops: 2 subtractions, 2 absolute-value accumulations):
+# 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / 4 cycles x 4 ops = 157.3 T ops/s
+PEAK_SAD_TOPS = 256 * 4 * 64 * 2.4e9 / 4 * 4 / 1e12
 PEAK_HBM_GBS = 8000.0
 
 
-def structured_image(h, w, seed, device):
-    """Smooth waves plus Gaussian noise, clipped to uint8 (the 'structured' synthetic image)."""
-    g = torch.Generator(device=device).manual_seed(seed)
-    y = torch.arange(h, device=device, dtype=torch.float32)[:, None]
-    x = torch.arange(w, device=device, dtype=torch.float32)[None, :]
-    v = (128 + 64 * torch.sin(2 * np.pi * x / 257) * torch.cos(2 * np.pi * y / 181)
-         + 32 * torch.sin(2 * np.pi * (x + y) / 1021) + 16 * torch.randn((h, w), device=device, generator=g))
-    return v.clamp(0, 255).to(torch.uint8)
-
-
-def cpu_baseline(blocks_sample, cb, n_decode):
-    """Reference arithmetic on the host: scipy cdist('cityblock') + argmin in 65 536-vector chunks
-    (VQ_Full.py:124-125) and the decode loop restated in C (VQ_Full.py:157-169), one core."""
+# ---------------------------------------------------------------------------------------------------
+# CPU baseline (runs in a child process that never touches the GPU)
+# ---------------------------------------------------------------------------------------------------
+def _cpu_shard(args):
     from oracle import vq_oracle as o
+    blocks, cb = args
+    return o.scipy_encode_chunked(blocks, cb, chunk=65536)
+
+
+def cpu_baseline_main(path):
+    """Reference arithmetic on the host: scipy cdist('cityblock') + argmin in 65 536-vector chunks
+    (VQ_Full.py:124-125) and the decode loop restated in C (VQ_Full.py:157-169); one core, then the same
+    encode sharded over P worker processes."""
+    import multiprocessing as mp
+    from oracle import vq_oracle as o
+    z = np.load(path)
+    blocks, cb = z["blocks"], z["cb"]
+    n = blocks.shape[0]
     t0 = time.perf_counter()
-    labels = o.scipy_encode_chunked(blocks_sample, cb, chunk=65536)
+    labels = o.scipy_encode_chunked(blocks, cb, chunk=65536)
     t_enc = time.perf_counter() - t0
-    side = int(np.sqrt(n_decode))
+    side = int(np.sqrt(min(n, 1 << 20)))
     grid = labels[: side * side].astype(np.int32).reshape(side, side)
     t0 = time.perf_counter()
     o.decode_u8(grid, cb, BH, BW, 1)
     t_dec = time.perf_counter() - t0
-    n = blocks_sample.shape[0]
     per_vec = t_enc / n + t_dec / (side * side)
-    return dict(value=1.0 / per_vec, unit="block-vectors/s", cores=1, kind="port",
-                sample=f"{n} of the workload's block vectors: scipy cdist+argmin in 65536-vector chunks "
-                       f"({t_enc:.2f} s) + C restatement of the decode loop on {side * side} labels ({t_dec:.3f} s)",
-                encode_only=n / t_enc), labels
+    procs = max(1, min(16, os.cpu_count() or 1))
+    shards = [(blocks[i * n // procs:(i + 1) * n // procs], cb) for i in range(procs)]
+    with mp.get_context("fork").Pool(procs) as pool:
+        pool.map(_cpu_shard, [(blocks[:1024], cb)] * procs)          # start the workers, import scipy
+        t0 = time.perf_counter()
+        parts = pool.map(_cpu_shard, shards)
+        t_par = time.perf_counter() - t0
+    same = bool(np.array_equal(np.concatenate(parts), labels))
+    np.save(path + ".labels.npy", labels)
+    print(json.dumps(dict(
+        value=1.0 / per_vec, unit="block-vectors/s", cores=1, kind="port",
+        sample=f"{n} of the workload's block vectors: scipy cdist+argmin in 65536-vector chunks ({t_enc:.2f} s) "
+               f"+ C restatement of the decode loop on {side * side} labels ({t_dec:.3f} s), one core",
+        encode_only=n / t_enc,
+        all_cores=dict(value=n / t_par, unit="block-vectors/s (encode only)", cores=procs, seconds=t_par,
+                       labels_equal_one_core=same,
+                       sample=f"the same {n} vectors sharded over {procs} worker processes (reference arithmetic, "
+                              f"P = {procs} processes; this box exposes {os.cpu_count()} CPUs)"))))
+
+
+def run_cpu_baseline(blocks_h, cb_h):
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "cpu_sample.npz")
+        np.savez(path, blocks=blocks_h, cb=cb_h)
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-file", path],
+                             check=True, capture_output=True, text=True)
+        base = json.loads(out.stdout.strip().splitlines()[-1])
+        labels = np.load(path + ".labels.npy")
+    return base, labels
+
+
+# ---------------------------------------------------------------------------------------------------
+# GPU side
+# ---------------------------------------------------------------------------------------------------
+def structured_image(h, w, seed, device, channels=1):
+    """Smooth waves plus Gaussian noise, clipped to uint8 (the 'structured' synthetic image); with three
+    channels the waves are phase-shifted per channel."""
+    import torch
+    g = torch.Generator(device=device).manual_seed(seed)
+    y = torch.arange(h, device=device, dtype=torch.float32)[:, None]
+    x = torch.arange(w, device=device, dtype=torch.float32)[None, :]
+    planes = []
+    for c in range(channels):
+        ph = 0.7 * c
+        v = (128 + 64 * torch.sin(2 * np.pi * x / 257 + ph) * torch.cos(2 * np.pi * y / 181 - ph)
+             + 32 * torch.sin(2 * np.pi * (x + y) / 1021 + 2 * ph)
+             + 16 * torch.randn((h, w), device=device, generator=g))
+        planes.append(v.clamp(0, 255).to(torch.uint8))
+    return planes[0] if channels == 1 else torch.stack(planes, dim=-1).contiguous()
+
+
+def iid_image(h, w, seed, device):
+    import torch
+    g = torch.Generator(device=device).manual_seed(seed)
+    return torch.randint(0, 256, (h, w), device=device, generator=g, dtype=torch.uint8)
+
+
+def event_ms(fn, reps, device):
+    import torch
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize(device)
+    return float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+
+def search_profile(eng, img, bh, bw, cb, reps, device):
+    """Timings and statistics of the search on one (image, codebook): the filter kernel alone (HIP events on
+    its stream), the fix-up alone, the evaluated share of all (vector, codeword) pairs."""
+    import torch
+    C = 1 if img.dim() == 2 else img.shape[2]
+    K, d = cb.shape
+    srt, (N, d2) = eng.sort_image(img, bh, bw)
+    assert d2 == d
+    blocks = None
+    pruned = srt is not None and eng.prune_supported(K, d)
+    if not pruned:
+        blocks = eng.blocks_from_image(img, bh, bw)
+        srt = None
+    prepared = eng.prepare_codebook(cb, N)
+    labels = torch.empty(N, dtype=torch.int32, device=device)
+    kw = dict(labels=labels, sorted=srt, shape=(N, d))
+    for _ in range(2):
+        eng.encode_prepared(blocks, prepared, **kw)
+    filter_ms = event_ms(lambda: eng.encode_prepared(blocks, prepared, phases=1, **kw), reps, device)
+    queued, pairs_eval = eng.search_statistics(prepared, N)
+    fixup_ms = event_ms(lambda: eng.encode_prepared(blocks, prepared, phases=2, **kw), reps, device)
+    both_ms = event_ms(lambda: eng.encode_prepared(blocks, prepared, **kw), reps, device)
+    pairs_all = float(N) * K
+    pairs_eval = float(pairs_eval)
+    ops_exec = 2.0 * d * pairs_eval
+    out = dict(K=K, d=d, N=N, pruned_search=bool(pruned), filter_kernel_ms=filter_ms, fixup_kernel_ms=fixup_ms,
+               search_ms=both_ms, vectors_per_s=N / (both_ms * 1e-3), queued_for_fp64_frac=queued / N,
+               evaluated_pair_frac=pairs_eval / pairs_all,
+               executed_tops=ops_exec / (filter_ms * 1e-3) / 1e12,
+               frac_of_sad_ceiling=ops_exec / (filter_ms * 1e-3) / 1e12 / PEAK_SAD_TOPS,
+               algorithmic_tops=2.0 * d * pairs_all / (filter_ms * 1e-3) / 1e12)
+    return out, labels, srt, prepared, blocks
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--cpu-sample", type=int, default=1 << 21, help="block vectors timed on the host (0 = skip)")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--cpu-sample", type=int, default=1 << 22, help="block vectors timed on the host (0 = skip)")
+    ap.add_argument("--no-shapes", action="store_true", help="skip the other-shape and full-training measurements")
+    ap.add_argument("--cpu-baseline-file", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_file:
+        cpu_baseline_main(args.cpu_baseline_file)
+        return
 
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
-    if args.gpus != world:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     group = None
@@ -85,6 +200,7 @@ def main():
         group = dist.group.WORLD
 
     from vector_quantization_amd import HipEngine, train_lbg, lbg_iteration
+    from vector_quantization_amd import _lib
     from vector_quantization_amd.lbg import shards_chunk_aligned
     eng = HipEngine(device)
 
@@ -93,24 +209,18 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(device)
 
-    # ---- untimed set-up: image, block vectors, a trained codebook ------------------------------
+    # ---- untimed set-up: the image and a trained codebook ---------------------------------------------
     img = structured_image(H, W, seed=1000 + rank, device=device)
-    blocks = eng.blocks_from_image(img, BH, BW)
-    N, d = blocks.shape
     crop = eng.blocks_from_image(structured_image(2048, 2048, seed=0, device=device), BH, BW)
     cb = train_lbg(eng, crop, K_CODEBOOK, log=None).codebook          # same codebook on every rank (seed 0)
-    prepared = eng.prepare_codebook(cb, blocks.shape[0])
-    labels = torch.empty(N, dtype=torch.int32, device=device)
     nr, nc = H // BH, W // BW
-    sorted_buf = eng.sort_blocks(blocks)                                 # allocated once, refilled every step
-
-    def encode():
-        # the window sort is part of the encode: the step starts from the plain block matrix
-        srt = eng.sort_blocks(blocks, out=sorted_buf)
-        eng.encode_prepared(blocks, prepared, labels=labels, sorted=srt)
+    N, d = nr * nc, BH * BW
+    labels = torch.empty(N, dtype=torch.int32, device=device)
+    scratch = torch.empty(_lib.lib.vq_sorted_bytes(d, N), dtype=torch.uint8, device=device)
 
     def step():
-        encode()
+        # image -> sorted block vectors -> prepared codebook -> pruned search -> fp64 fix-up -> decode
+        eng.encode_image(img, BH, BW, cb, scratch=scratch, labels=labels)
         return eng.decode(labels.view(nr, nc), cb, BH, BW, 1)
 
     for _ in range(args.warmup):
@@ -126,115 +236,114 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(t.item())
     value = world * N * args.steps / elapsed
+    labels_step = labels.clone()
 
-    # ---- the dominant kernel alone, HIP events on the launch stream ------------------------------
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    for a, b in ev:
-        a.record()
-        encode()
-        b.record()
-    torch.cuda.synchronize(device)
-    enc_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    labels_pruned = labels.clone()
-    # the two parts of the encode on their own: window sort (HBM-bound), pruned search + fix-up (VALU-bound)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    for a, b in ev:
-        a.record()
-        eng.sort_blocks(blocks, out=sorted_buf)
-        b.record()
-    torch.cuda.synchronize(device)
-    sort_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    for a, b in ev:
-        a.record()
-        eng.encode_prepared(blocks, prepared, labels=labels, sorted=sorted_buf)
-        b.record()
-    torch.cuda.synchronize(device)
-    search_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    for a, b in ev:
-        a.record()
-        eng.encode_prepared(blocks, prepared, labels=labels)              # every codeword for every vector
-        b.record()
-    torch.cuda.synchronize(device)
-    enc_full_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    full_equals_pruned = bool(torch.equal(labels, labels_pruned))
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    for a, b in ev:
-        a.record()
-        eng.decode(labels.view(nr, nc), cb, BH, BW, 1)
-        b.record()
-    torch.cuda.synchronize(device)
-    dec_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    ops = 2.0 * K_CODEBOOK * d * N                  # subtract + |.|-accumulate per (vector, codeword, element)
-    achieved = ops / (search_ms * 1e-3) / 1e12
-    # HBM bytes per launch of the same kernels on the same workload, from separate rocprofv3 --pmc passes
-    # (FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as is); see profiles/
-    traffic, pmc, pmc_note = None, None, "no PMC summary found under profiles/"
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_encode_summary.json")
+    # ---- the kernels of the step on their own, HIP events on the launch stream ---------------------------
+    reps = max(20, min(args.steps, 200))
+    prof, labels_p, srt, prepared, _ = search_profile(eng, img, BH, BW, cb, reps, device)
+    step_labels_equal = bool(torch.equal(labels_p, labels_step))
+    # the same launch pair without pruning (every codeword for every vector), as a cross-check of labels and as
+    # the measure of what pruning saves
+    blocks = eng.blocks_from_image(img, BH, BW)
+    lab_full = torch.empty_like(labels)
+    full_ms = event_ms(lambda: eng.encode_prepared(blocks, prepared, labels=lab_full, phases=1), reps, device)
+    _, pairs_full = eng.search_statistics(prepared, N)
+    eng.encode_prepared(blocks, prepared, labels=lab_full)
+    full_equals_pruned = bool(torch.equal(lab_full, labels_step))
+    full_ops = 2.0 * d * pairs_full
+    sort_ms = event_ms(lambda: eng.sort_image(img, BH, BW, out=scratch), reps, device)
+    prep_ms = event_ms(lambda: eng.prepare_codebook(cb, 0), reps, device)
+    dec_ms = event_ms(lambda: eng.decode(labels.view(nr, nc), cb, BH, BW, 1), reps, device)
+    enc_ms = event_ms(lambda: eng.encode_image(img, BH, BW, cb, scratch=scratch, labels=labels), reps, device)
+
+    # HBM bytes per launch from separate rocprofv3 --pmc passes of this library build, when a summary made
+    # from the same libvqhip.so is committed under profiles/ (FETCH_SIZE doubled per the gfx950 correction)
+    traffic, pmc_note = None, "no PMC summary for this library build under profiles/"
+    lib_sha = hashlib.sha256(open(_lib.library_path(), "rb").read()).hexdigest()[:16]
+    pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+    pmc = None
     if os.path.isfile(pmc_path):
         with open(pmc_path) as f:
             pmc = json.load(f)
-        by_kernel = pmc["hbm_bytes_by_kernel"]
-        traffic = sum(v for k, v in by_kernel.items() if not k.startswith("k_window_sort"))
-        pmc_note = ("traffic (search + fix-up launches), valu_busy_frac and evaluated_pair_frac from profiles/r01_pmc_*.csv "
-                    f"(rocprofv3 --pmc, same workload); algorithmic bytes per launch = {N * (d + 4 + 2)} "
-                    "(row + label + 2-byte origin per vector)")
-    search_alg_bytes = N * (d + 4 + 2)
-    roofline = dict(bound="valu", achieved=achieved, peak=PEAK_VALU_TOPS, unit="TFLOP/s",
-                    frac=achieved / PEAK_VALU_TOPS, traffic=traffic,
-                    kernel="k_assign_fast<8,4,packed,pruned> + k_fixup (the two launches of vq_encode_l1_prepared "
-                           "on window-sorted vectors)",
-                    kernel_ms=search_ms, full_search_ms=enc_full_ms,
-                    full_search_achieved=ops / (enc_full_ms * 1e-3) / 1e12,
-                    full_search_frac=ops / (enc_full_ms * 1e-3) / 1e12 / PEAK_VALU_TOPS,
-                    full_search_labels_equal=full_equals_pruned,
-                    algorithmic_ops_per_vector=2 * K_CODEBOOK * d,
-                    algorithmic_bytes_per_vector=d + 4 + 2,
-                    valu_busy_frac=(pmc["full_search"]["valu_busy_frac"] if pmc else None),
-                    evaluated_pair_frac=(pmc["pruned_search"]["share_of_full_search_valu"] if pmc else None),
-                    note="ops = one subtract + one |.|-accumulate per (vector, codeword, element), counted for ALL K*N "
-                         "pairs; peak = the fp32 vector peak counted without FMA (157.3 / 2). Two effects put frac "
-                         "above 1: the integer v_sad_u16 retires two such pairs per lane-instruction, and the search "
-                         "skips every codeword whose element sum is provably too far from the vector's "
-                         "(|sum x - sum c| <= L1 distance; vectors sorted by element sum inside windows of 8192, "
-                         "codebook sorted by element sum), so it executes only evaluated_pair_frac of the "
-                         "instructions of the full search while returning the same labels. full_search_* is the "
-                         "same launch pair without that pruning and valu_busy_frac the share of SIMD issue cycles "
-                         "its VALU instructions occupy. " + pmc_note)
-    sort_alg_bytes = N * (2 * d + 2)
-    sort = dict(bound="hbm", kernel="k_window_sort (vq_blocks_sort)", kernel_ms=sort_ms,
-                achieved=sort_alg_bytes / (sort_ms * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
-                frac=sort_alg_bytes / (sort_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                traffic=(sum(v for k, v in pmc["hbm_bytes_by_kernel"].items() if k.startswith("k_window_sort"))
-                         if pmc else None),
-                algorithmic_bytes_per_vector=2 * d + 2,
-                note="reads every row once, writes it once at its sorted place plus a 2-byte origin; the scattered "
-                     "16-byte stores are the write amplification seen in traffic")
-    decode_gbs = (N * (d + 4)) / (dec_ms * 1e-3) / 1e9
+        if pmc.get("library_sha256_16") != lib_sha:
+            pmc_note = (f"profiles/r02_pmc_summary.json was made from library {pmc.get('library_sha256_16')}, this run "
+                        f"uses {lib_sha}: not reported")
+            pmc = None
+        else:
+            pmc_note = "HBM traffic per launch from profiles/r02_pmc_*.csv (rocprofv3 --pmc passes of this library build)"
+
+    def pmc_bytes(prefix):
+        if not pmc:
+            return None
+        v = [b for k, b in pmc["hbm_bytes_by_kernel"].items() if k.startswith(prefix)]
+        return float(sum(v)) if v else None
+
+    traffic = pmc_bytes("k_assign_fast")
+    roofline = dict(
+        bound="valu", unit="TFLOP/s",
+        kernel="k_assign_fast<DP2=8, R=4, packed keys, scalar-load codewords, PRUNE> (the filter launch of "
+               "vq_encode_l1_prepared / vq_encode_l1_img on window-sorted vectors)",
+        kernel_ms=prof["filter_kernel_ms"],
+        achieved=prof["executed_tops"], peak=PEAK_SAD_TOPS, frac=prof["frac_of_sad_ceiling"], traffic=traffic,
+        evaluated_pair_frac=prof["evaluated_pair_frac"],
+        algorithmic_speedup=1.0 / prof["evaluated_pair_frac"],
+        algorithmic_tops_all_pairs=prof["algorithmic_tops"],
+        algorithmic_ops_per_vector=2 * K_CODEBOOK * d, algorithmic_bytes_per_vector=d + 4 + 2,
+        queued_for_fp64_frac=prof["queued_for_fp64_frac"],
+        fixup_kernel_ms=prof["fixup_kernel_ms"],
+        full_search_kernel_ms=full_ms, full_search_executed_tops=full_ops / (full_ms * 1e-3) / 1e12,
+        full_search_frac=full_ops / (full_ms * 1e-3) / 1e12 / PEAK_SAD_TOPS,
+        full_search_labels_equal=full_equals_pruned, step_labels_equal_profiled=step_labels_equal,
+        note="L1 distance has no GEMM form, so the bound is the vector ALU, not MFMA or HBM. achieved = EXECUTED "
+             "subtract + |.|-accumulate ops (2*d per evaluated (vector, codeword) pair; pairs counted by the kernel "
+             "itself: rows each wave evaluated x its 256 vectors) / the filter kernel's mean duration (HIP events "
+             "around that launch alone). peak = the v_sad_u16 issue ceiling: one wave64 instruction per 4 cycles per "
+             "SIMD (measured, profiles/r02_valu_ubench.txt; no operand form issues faster), two |x-c| accumulations "
+             "per lane = 157.3 T ops/s. Besides its d/2 SADs every pair costs 3 more instructions of the same issue "
+             "class (key, median, minimum), so 8/11 = 0.73 is the ceiling of frac at d = 16. The pruned search "
+             "evaluates only evaluated_pair_frac of all N*K pairs (codewords whose element sum differs from the "
+             "vector's by more than the best distance so far cannot win), with identical labels: that gain is "
+             "algorithmic_speedup, not part of frac. " + pmc_note)
+    sort_alg = N * (2 * d + 2)
+    dec_alg = N * (d + 4)
+    hbm_kernels = {
+        "image_sort": dict(bound="hbm", kernel="k_window_sort_lds<4, image source> (vq_blocks_sort_img)", kernel_ms=sort_ms,
+                           achieved=sort_alg / (sort_ms * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
+                           frac=sort_alg / (sort_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, traffic=pmc_bytes("k_window_sort"),
+                           algorithmic_bytes_per_vector=2 * d + 2,
+                           note="reads every pixel once, writes every row once at its sorted place plus a 2-byte origin"),
+        "decode": dict(bound="hbm", kernel="k_decode_blockrows_u8<16> (vq_decode_u8)", kernel_ms=dec_ms,
+                       achieved=dec_alg / (dec_ms * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
+                       frac=dec_alg / (dec_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, traffic=pmc_bytes("k_decode"),
+                       algorithmic_bytes_per_vector=d + 4),
+        "codebook_prepare": dict(kernel="k_prepare", kernel_ms=prep_ms, note="K*d entries; latency-bound"),
+    }
 
     # ---- LBG iterations (fused assign + accumulate, exchange, centroid update) ----------------------
     n_total = world * N
     cur = cb
-    # every rank's shard size, exchanged once (train_lbg does the same before its loop)
-    shard_info = shards_chunk_aligned(N, group) if distributed else None
-    for _ in range(2):
-        cur, _ = lbg_iteration(eng, blocks, cur, n_total, group, shard_info, sorted=sorted_buf)
+    shard_info = shards_chunk_aligned(N, group, device) if distributed else None
+    for _ in range(3):
+        cur, _ = lbg_iteration(eng, blocks, cur, n_total, group, shard_info, sorted=srt)
     barrier()
     t0 = time.perf_counter()
     lbg_steps = max(5, args.steps // 2)
     for _ in range(lbg_steps):
         # the vectors do not change between iterations: the sort made above serves all of them
-        cur, _ = lbg_iteration(eng, blocks, cur, n_total, group, shard_info, sorted=sorted_buf)
+        cur, _ = lbg_iteration(eng, blocks, cur, n_total, group, shard_info, sorted=srt)
     barrier()
     lbg_elapsed = time.perf_counter() - t0
     t = torch.tensor([lbg_elapsed], dtype=torch.float64, device=device)
     if distributed:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     lbg_elapsed = float(t.item())
+    lbg = {"iters_per_s": lbg_steps / lbg_elapsed, "vectors_per_s": n_total * lbg_steps / lbg_elapsed,
+           "ms_per_iter": lbg_elapsed / lbg_steps * 1e3, "vectors_total": n_total, "timed_iterations": lbg_steps,
+           "exchange": ("one collective per iteration on int64 [K*d sums | K counts] + fp64 per-chunk distance sums"
+                        if distributed else "none (1 GPU)")}
 
     result = {
-        "metric": "block-vectors encoded/sec (encode+decode step; LBG iter/sec in `lbg`) at K=256,dim=16",
+        "metric": "block-vectors encoded/sec (image -> labels -> decoded image; LBG iter/sec in `lbg`) at K=256,dim=16",
         "value": value,
         "unit": "block-vectors/s",
         "n_gpus": world,
@@ -247,28 +356,63 @@ def main():
         "dtype": "u16 fixed-point SAD filter + f64 re-check (labels identical to the all-f64 search)",
         "data": "synthetic",
         "config": {"workload": "configs[1]: synthetic 8192x8192 grayscale per GPU, 4x4 blocks (dim 16), K=256, "
-                               "encode+decode", "vectors_per_gpu": N, "K": K_CODEBOOK, "dim": d,
+                               "encode+decode starting from the image", "vectors_per_gpu": N, "K": K_CODEBOOK, "dim": d,
                    "parallelism": f"dp{world} (block vectors sharded by image, codebook replicated)"},
+        "encode_ms": enc_ms,
         "encode_vectors_per_s_per_gpu": N / (enc_ms * 1e-3),
         "decode_vectors_per_s_per_gpu": N / (dec_ms * 1e-3),
-        "decode_gbs": decode_gbs,
-        "decode_frac_of_hbm_peak": decode_gbs / PEAK_HBM_GBS,
-        "lbg": {"iters_per_s": lbg_steps / lbg_elapsed, "vectors_per_s": n_total * lbg_steps / lbg_elapsed,
-                "ms_per_iter": lbg_elapsed / lbg_steps * 1e3, "vectors_total": n_total,
-                "exchange": "one all-gather of int64 [K*d sums | K counts | fp64 per-chunk distance sums] per iteration" if distributed
-                else "none (1 GPU)"},
-        "encode_ms": enc_ms,
+        "step_kernels_ms": {"image_sort": sort_ms, "codebook_prepare": prep_ms, "search_filter": prof["filter_kernel_ms"],
+                            "search_fixup": prof["fixup_kernel_ms"], "decode": dec_ms},
+        "lbg": lbg,
         "roofline": roofline,
-        "sort": sort,
+        "hbm_kernels": hbm_kernels,
+        "library_sha256_16": lib_sha,
     }
+
+    if rank == 0 and world == 1 and not args.no_shapes:
+        shapes = {}
+        # worst case for pruning: uniform iid pixels (no spread of element sums to exploit)
+        iid = iid_image(H, W, 1, device)
+        cb_iid = train_lbg(eng, eng.blocks_from_image(iid[:1024, :1024].contiguous(), BH, BW), K_CODEBOOK, log=None).codebook
+        shapes["cfg2_iid_K256_d16"] = search_profile(eng, iid, BH, BW, cb_iid, 20, device)[0]
+        del iid
+        # K = 1024, d = 16 (the codebook size of configs[2]) on the headline image
+        cb1k = train_lbg(eng, crop, 1024, log=None).codebook
+        shapes["K1024_d16"] = search_profile(eng, img, BH, BW, cb1k, 20, device)[0]
+        # the reference's default colour path: RGB 4x4 blocks, d = 48
+        rgb = structured_image(4096, 4096, 3, device, channels=3)
+        cb48 = train_lbg(eng, eng.blocks_from_image(rgb[:1024, :1024].contiguous(), 4, 4), 256, log=None).codebook
+        shapes["rgb4x4_K256_d48"] = search_profile(eng, rgb, 4, 4, cb48, 20, device)[0]
+        del rgb
+        # configs[4]: RGB 8x8 blocks, d = 192, K = 4096 (one GPU's share: 4096 x 4096 x 3, N = 262 144)
+        rgb8 = structured_image(4096, 4096, 5, device, channels=3)
+        cb192 = train_lbg(eng, eng.blocks_from_image(rgb8[:1024, :1024].contiguous(), 8, 8), 4096, log=None).codebook
+        shapes["cfg5_K4096_d192"] = search_profile(eng, rgb8, 8, 8, cb192, 5, device)[0]
+        del rgb8
+        result["shapes"] = shapes
+        # configs[2]: full LBG training to K = 1024 on a 16384 x 16384 image (N = 16 777 216), one GPU
+        big = structured_image(16384, 16384, 2, device)
+        bblocks = eng.blocks_from_image(big, BH, BW)
+        del big
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        res = train_lbg(eng, bblocks, 1024, log=None)
+        torch.cuda.synchronize(device)
+        t_train = time.perf_counter() - t0
+        its = int(sum(res.iters_per_stage))
+        result["lbg_full_training_cfg3"] = {
+            "workload": "configs[2]: 16384x16384 grayscale, 4x4 blocks (N = 16 777 216, dim 16), LBG to K = 1024, "
+                        "epsilon 0.01, threshold 0.001, max 100 iterations per stage",
+            "seconds": t_train, "iterations": its, "iters_per_stage": list(res.iters_per_stage),
+            "final_distortion": res.distortions[-1], "iterations_per_s": its / t_train,
+            "vector_iterations_per_s": its * float(bblocks.shape[0]) / t_train}
+        del bblocks
 
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         n_s = min(args.cpu_sample, N)
-        sample = blocks[:n_s].cpu().numpy()
-        cbh = cb.cpu().numpy()
-        base, cpu_labels = cpu_baseline(sample, cbh, min(n_s, 1 << 20))
+        base, cpu_labels = run_cpu_baseline(blocks[:n_s].cpu().numpy(), cb.cpu().numpy())
         result["cpu_baseline"] = base
-        result["cpu_labels_match_gpu"] = bool(np.array_equal(cpu_labels, labels[:n_s].cpu().numpy().astype(np.int64)))
+        result["cpu_labels_match_gpu"] = bool(np.array_equal(cpu_labels, labels_step[:n_s].cpu().numpy().astype(np.int64)))
     else:
         result["cpu_baseline"] = None
 

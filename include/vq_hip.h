@@ -106,16 +106,43 @@ size_t vq_sorted_bytes(int d, int64_t N);
 int vq_prune_supported(int K, int d);
 int vq_blocks_sort(const uint8_t *blocks, int64_t N, int d, void *sorted, size_t sorted_bytes, void *stream);
 
+/* Image-fused forms.  vq_blocks_sort_img does the work of vq_blocks_u8 followed by vq_blocks_sort in one
+ * pass -- padding (VQ_Full.py:23-33), block extraction (VQ_Full.py:51-57) and the window sort -- reading
+ * the image once and never writing the (N, d) block matrix; `sorted` (vq_sorted_bytes(d, N) bytes with
+ * N = ceil(H/bh) * ceil(W/bw), d = bh*bw*C <= 192) comes out exactly as those two calls would fill it.
+ * vq_encode_l1_img is Codebook.__init__'s block extraction plus Codebook.compress's search
+ * (VQ_Full.py:23-57, :124-125) on an image: labels (and min_dist, nullable) as vq_encode_l1 gives them for
+ * the image's block vectors.  `scratch` (at least vq_sorted_bytes(d, N) bytes, 16-byte aligned) receives
+ * the window-sorted rows when the pruned search serves (K, d), else the plain block matrix. */
+int vq_blocks_sort_img(const uint8_t *img, int H, int W, int C, int bh, int bw, int pad_mode, void *sorted,
+                       size_t sorted_bytes, void *stream);
+int vq_encode_l1_img(const uint8_t *img, int H, int W, int C, int bh, int bw, int pad_mode, const double *cb, int K,
+                     int32_t *labels, double *min_dist, void *scratch, size_t scratch_bytes, void *ws,
+                     size_t ws_bytes, void *stream);
+
 /* The same search split in two, for callers that encode many batches with one codebook (a batch of
  * images, repeated benchmark steps): vq_codebook_prepare fills ws from cb once (one small launch),
  * vq_encode_l1_prepared then runs VQ_MODE_FAST's two kernels (filter, fp64 fix-up) per batch.  ws must not
  * be handed to any other call in between; cb must still hold the same codebook.  Only dimensions
  * d <= 192 (the SAD filter kernels) are served; others return VQ_E_UNSUPPORTED.  `sorted` is null
- * or the buffer vq_blocks_sort filled from the same blocks (sorted_bytes: its size). */
+ * or the buffer vq_blocks_sort / vq_blocks_sort_img filled from the same blocks (sorted_bytes: its
+ * size).  When `sorted` is given and vq_prune_supported(K, d), `blocks` is not read and may be null. */
 int vq_codebook_prepare(const double *cb, int K, int d, void *ws, size_t ws_bytes, void *stream);
 int vq_encode_l1_prepared(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d,
                           const double *cb, int K, int32_t *labels, double *min_dist, void *ws, size_t ws_bytes,
                           void *stream);
+
+/* For profiling and benchmarks: vq_encode_l1_prepared with its two launches selectable, phases = 1 the
+ * filter (queue reset + SAD search; labels / min_dist of the vectors it settles), 2 the fp64 fix-up of the
+ * vectors the last filter pass queued in this ws, 3 both (= vq_encode_l1_prepared).  After a filter pass
+ * the workspace holds two statistics per sub-queue slot q (q = 0 .. 63) at byte offset
+ * vq_workspace_counters_offset(K, d, N) + 64 * q: at byte 0 a uint32 count of vectors queued for the
+ * fix-up, at byte 8 a uint64 count of the (vector, codeword) pairs whose distance the filter evaluated
+ * (N * K rounded up to the kernel's batch without pruning). */
+int vq_encode_l1_prepared_phases(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d,
+                                 const double *cb, int K, int32_t *labels, double *min_dist, int phases, void *ws,
+                                 size_t ws_bytes, void *stream);
+size_t vq_workspace_counters_offset(int K, int d, int64_t N);
 
 /* One LBG assignment pass, fused.  Replaces VQ_Full.py:77-90 up to the division: assigns every
  * vector as vq_encode_l1 does (labels: N int32, min_dist: N doubles, both overwritten), ADDS into
@@ -125,8 +152,9 @@ int vq_encode_l1_prepared(const uint8_t *blocks, const void *sorted, size_t sort
  * into, so the caller zeroes them first (and may all-reduce them across GPUs afterwards).
  * chunk_sums (nullable) receives the ceil(N / 8192) per-chunk sums dist_sum is the left-to-right
  * total of; ranks that hold consecutive, 8192-aligned shards can concatenate them to reproduce
- * the single-process value.  `sorted` is null or the buffer vq_blocks_sort filled from the same
- * blocks (used by VQ_MODE_FAST only). */
+ * the single-process value.  `sorted` is null or the buffer vq_blocks_sort / vq_blocks_sort_img filled
+ * from the same blocks (used by VQ_MODE_FAST only; when it is given and vq_prune_supported(K, d),
+ * `blocks` is not read and may be null). */
 int vq_lbg_accum(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d,
                  const double *cb, int K, uint64_t *sums, uint64_t *counts, int32_t *labels, double *min_dist,
                  double *dist_sum, double *chunk_sums, int mode, void *ws, size_t ws_bytes, void *stream);

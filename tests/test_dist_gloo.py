@@ -23,7 +23,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, case, splits, out_dir):
+def _worker(rank, world, port, case, splits, out_dir, allreduce_from=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -33,6 +33,9 @@ def _worker(rank, world, port, case, splits, out_dir):
         from oracle_engine import OracleEngine
         from vqtest_util import load_golden
         from vector_quantization_amd import train_lbg
+        import vector_quantization_amd.lbg as lbg_mod
+        if allreduce_from is not None:
+            lbg_mod.ALLREDUCE_FROM_BYTES = allreduce_from      # 0: every exchange takes the all-reduce route
         g = load_golden(case)
         blocks = torch.from_numpy(g["blocks"])
         lo, hi = splits[rank], splits[rank + 1]
@@ -43,16 +46,20 @@ def _worker(rank, world, port, case, splits, out_dir):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("allreduce_from", [None, 0])
 @pytest.mark.parametrize("case,frac", [("man_2x2_k5", 0.5), ("synth_iid_128_4x4_k32", 0.3), ("luffy_2x2_k16", 0.0),
                                        ("luffy_2x2_k16", -8192)])
-def test_sharded_training_equals_single_process(tmp_path, case, frac):
+def test_sharded_training_equals_single_process(tmp_path, case, frac, allreduce_from):
+    """allreduce_from None: the small-payload route (one all-gather); 0: the large-payload route (integer
+    all-reduce + gather of the distance partials).  Both must give the reference's codebook."""
     from vqtest_util import load_golden
     g = load_golden(case)
     N = g["blocks"].shape[0]
     # frac 0.0: rank 0 holds no vectors at all; negative: an absolute, 8192-aligned cut
     cut = -frac if frac < 0 else int(N * frac)
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), case, [0, cut, N], str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), case, [0, cut, N], str(tmp_path), allreduce_from), nprocs=world,
+             join=True)
     r0 = np.load(tmp_path / "rank0.npz")
     r1 = np.load(tmp_path / "rank1.npz")
     assert np.array_equal(r0["codebook"], r1["codebook"])            # every rank ends with the same codebook

@@ -237,3 +237,47 @@ def test_emu_pruned_fixup(eng, oracle, K, d, N, use_sorted):
     assert np.array_equal(labels.numpy(), want["labels"])
     assert np.array_equal(a[: K * d].reshape(K, d), want["sums"]) and np.array_equal(a[K * d:], want["counts"])
     assert dist.item() == oracle.numpy_sum(want["min_dist"])
+
+
+@pytest.mark.parametrize("shape,bh,bw,pad", [((64, 96, 1), 4, 4, 0), ((37, 53, 1), 4, 4, 0), ((37, 53, 1), 4, 4, 1), ((30, 22, 3), 2, 2, 0),
+                                             ((19, 27, 1), 2, 2, 1), ((33, 20, 3), 4, 4, 0), ((21, 50, 1), 2, 4, 0), ((40, 36, 2), 3, 3, 0),
+                                             ((400, 400, 1), 4, 4, 0)])
+def test_emu_sort_image_equals_extract_then_sort(eng, oracle, shape, bh, bw, pad):
+    """Image -> sorted rows in one pass: a valid window-sorted copy of exactly the block matrix that
+    block extraction gives (word and byte paths, both pad modes, ragged sizes, more than one window)."""
+    rng = np.random.default_rng(shape[0] * 7 + shape[1] + bh)
+    img = np.clip(rng.integers(0, 200, size=shape[:2] + (1,)) + rng.integers(0, 56, size=shape), 0, 255).astype(np.uint8)
+    blocks = oracle.blocks_u8(img, bh, bw, pad)
+    buf, (N, d) = eng.sort_image(T(img), bh, bw, pad)
+    assert (N, d) == blocks.shape
+    _check_sorted(buf, blocks)
+
+
+@pytest.mark.parametrize("shape,bh,bw,K", [((120, 136, 1), 4, 4, 64), ((50, 61, 3), 2, 2, 40), ((64, 64, 3), 4, 4, 48), ((70, 90, 1), 4, 4, 8),
+                                           ((40, 40, 3), 8, 8, 33)])
+def test_emu_encode_image(eng, oracle, shape, bh, bw, K):
+    """vq_encode_l1_img (pruned search on rows sorted straight from the image; plain search for shapes the
+    pruned one does not serve) and one LBG pass without the block matrix, on data full of near-ties."""
+    rng = np.random.default_rng(K * 5 + bh)
+    d = bh * bw * shape[2]
+    base = np.clip(rng.random((max(2, K // 3), 1)) * 255 + rng.normal(0, 15, (max(2, K // 3), d)), 0, 255)
+    cb = base[rng.integers(0, len(base), K)] + rng.choice([0.0, 0.001, -0.002, 0.5], size=(K, 1))
+    img = np.clip(rng.integers(0, 200, size=shape[:2] + (1,)) + rng.integers(0, 56, size=shape), 0, 255).astype(np.uint8)
+    blocks = oracle.blocks_u8(img, bh, bw, 0)
+    blocks[: len(blocks) // 2] = np.clip(np.rint(cb[rng.integers(0, K, len(blocks) // 2)]), 0, 255).astype(np.uint8)
+    # put the edited vectors back into the image so that image and blocks agree (sizes are multiples of the block)
+    if shape[0] % bh == 0 and shape[1] % bw == 0:
+        nr, nc = shape[0] // bh, shape[1] // bw
+        img = np.ascontiguousarray(blocks.reshape(nr, nc, bh, bw, shape[2]).swapaxes(1, 2).reshape(shape))
+    else:
+        blocks = oracle.blocks_u8(img, bh, bw, 0)
+    want = oracle.lbg_iter(blocks, cb)
+    got_l, got_d = eng.encode_image(T(img), bh, bw, T(cb), want_dist=True)
+    assert np.array_equal(got_l.numpy(), want["labels"]) and np.array_equal(got_d.numpy(), want["min_dist"])
+    if eng.prune_supported(K, d):
+        srt, nd = eng.sort_image(T(img), bh, bw)
+        acc, dist, labels = eng.lbg_accum(None, T(cb), want_labels=True, mode=1, sorted=srt, shape=nd)
+        a = acc.numpy().astype(np.uint64)
+        assert np.array_equal(labels.numpy(), want["labels"])
+        assert np.array_equal(a[: K * d].reshape(K, d), want["sums"]) and np.array_equal(a[K * d:], want["counts"])
+        assert dist.item() == oracle.numpy_sum(want["min_dist"])

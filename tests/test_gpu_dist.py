@@ -67,3 +67,75 @@ def test_two_ranks_equal_one_gpu(tmp_path, cut, oracle):
         assert np.array_equal(r0["dist"], np.array(single.distortions))
     else:
         assert np.allclose(r0["dist"], np.array(single.distortions), rtol=1e-12, atol=0)
+
+
+def _nccl_worker(rank, world, port, cut, out_dir, allreduce_from):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        from vector_quantization_amd import HipEngine, train_lbg
+        import vector_quantization_amd.lbg as lbg_mod
+        if allreduce_from is not None:
+            lbg_mod.ALLREDUCE_FROM_BYTES = allreduce_from
+        blocks = _make_blocks()
+        bounds = [0, cut, len(blocks)]
+        eng = HipEngine(f"cuda:{rank}")
+        shard = torch.from_numpy(blocks[bounds[rank]:bounds[rank + 1]].copy()).to(f"cuda:{rank}")
+        res = train_lbg(eng, shard, 32, group=dist.group.WORLD, log=None)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), codebook=res.codebook.cpu().numpy(),
+                 iters=np.array(res.iters_per_stage), dist=np.array(res.distortions))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("allreduce_from", [None, 0])
+def test_two_gpus_rccl_equal_one_gpu(tmp_path, allreduce_from):
+    """The same sharded loop with one rank per GPU over RCCL (backend "nccl"): needs two GPUs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from vector_quantization_amd import HipEngine, train_lbg
+    blocks = _make_blocks()
+    single = train_lbg(HipEngine("cuda:0"), torch.from_numpy(blocks).to("cuda:0"), 32, log=None)
+    mp.spawn(_nccl_worker, args=(2, _free_port(), 2 * 8192, str(tmp_path), allreduce_from), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(r0["codebook"], r1["codebook"])
+    assert np.array_equal(r0["codebook"], single.codebook.cpu().numpy())
+    assert list(r0["iters"]) == single.iters_per_stage
+    assert np.array_equal(r0["dist"], np.array(single.distortions))
+
+
+def _nccl_one_gpu_worker(rank, world, port, out_dir):
+    """RCCL with a single rank: the collectives of the exchange run on device tensors through the nccl
+    backend (world size 1), so that code path executes on a one-GPU box too."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        from vector_quantization_amd import HipEngine, train_lbg
+        import vector_quantization_amd.lbg as lbg_mod
+        blocks = torch.from_numpy(_make_blocks()).to("cuda:0")
+        eng = HipEngine("cuda:0")
+        out = {}
+        for name, thr in (("gather", 1 << 40), ("allreduce", 0)):
+            lbg_mod.ALLREDUCE_FROM_BYTES = thr
+            res = train_lbg(eng, blocks, 32, group=dist.group.WORLD, log=None)
+            out[name + "_cb"] = res.codebook.cpu().numpy()
+            out[name + "_dist"] = np.array(res.distortions)
+        np.savez(os.path.join(out_dir, "nccl1.npz"), **out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_exchange_world_size_one(tmp_path, oracle):
+    blocks = _make_blocks()
+    ref = oracle.lbg_train(blocks, 32)
+    mp.spawn(_nccl_one_gpu_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    r = np.load(tmp_path / "nccl1.npz")
+    for name in ("gather", "allreduce"):
+        assert np.array_equal(r[name + "_cb"], ref["codebook"])
+        assert np.array_equal(r[name + "_dist"], ref["distortions"])

@@ -601,3 +601,80 @@ def test_rgb_8x8_k4096_training_and_encode_match_reference(tmp_path, capsys):
     eng2 = cb._engine
     lab_x, mind_x = eng2.encode(cb._blocks_dev, dev(g["codebook"]), want_dist=True, mode=0)
     assert np.array_equal(lab_x.cpu().numpy().reshape(labels.shape), g["labels"])
+
+
+# ---------------------------------------------------------------------------------------------------
+# image-fused entry points: image -> sorted rows in one pass, labels straight from the image
+# ---------------------------------------------------------------------------------------------------
+def test_sort_image_golden(eng, train_case):
+    g = train_case
+    N, d = g["blocks"].shape
+    if d > 192:
+        pytest.skip("beyond the fast kernels")
+    buf, nd = eng.sort_image(dev(g["img"]), int(g["bh"]), int(g["bw"]))
+    assert nd == (N, d)
+    rows, perm = _sorted_parts(buf, N, d)
+    for w0 in range(0, N, 8192):
+        n = min(8192, N - w0)
+        p = perm[w0: w0 + n].astype(np.int64)
+        assert np.array_equal(np.sort(p), np.arange(n))
+        assert np.array_equal(rows[w0: w0 + n], g["blocks"][w0 + p])
+
+
+@pytest.mark.parametrize("shape,bh,bw", [((7, 5, 3), 2, 2), ((33, 17, 1), 4, 4), ((64, 64, 3), 8, 8), ((9, 9, 1), 3, 3),
+                                         ((130, 67, 3), 3, 5), ((16, 20, 2), 4, 2), ((515, 770, 1), 4, 4), ((300, 301, 1), 2, 2)])
+@pytest.mark.parametrize("pad_mode", [0, 1])
+def test_sort_image_ragged(eng, oracle, shape, bh, bw, pad_mode):
+    rng = np.random.default_rng(hash((shape, bh, bw)) & 0xffff)
+    img = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    blocks = oracle.blocks_u8(img, bh, bw, pad_mode)
+    N, d = blocks.shape
+    buf, nd = eng.sort_image(dev(img), bh, bw, pad_mode)
+    assert nd == (N, d)
+    rows, perm = _sorted_parts(buf, N, d)
+    for w0 in range(0, N, 8192):
+        n = min(8192, N - w0)
+        p = perm[w0: w0 + n].astype(np.int64)
+        assert np.array_equal(np.sort(p), np.arange(n))
+        assert np.array_equal(rows[w0: w0 + n], blocks[w0 + p])
+
+
+def test_encode_image_golden(eng, train_case):
+    """Labels straight from the image equal the reference's labels for the image's block vectors; the
+    per-vector distances equal the reference's where the fixture holds them."""
+    g = train_case
+    if g["blocks"].shape[1] > 192:
+        pytest.skip("beyond the fast kernels")
+    labels = eng.encode_image(dev(g["img"]), int(g["bh"]), int(g["bw"]), dev(g["codebook"]))
+    assert np.array_equal(labels.cpu().numpy().astype(np.int64).reshape(g["labels"].shape), g["labels"])
+    if "it_cb_in" in g:
+        labels, mind = eng.encode_image(dev(g["img"]), int(g["bh"]), int(g["bw"]), dev(g["it_cb_in"]), want_dist=True)
+        assert np.array_equal(labels.cpu().numpy().astype(np.int64), g["it_labels"])
+        assert np.array_equal(mind.cpu().numpy(), g["it_mind"])
+
+
+def test_lbg_iteration_from_sorted_image_only(eng, train_case):
+    """One LBG pass with the block matrix never built (sorted rows from the image, blocks = None)."""
+    g = train_case
+    if "it_cb_in" not in g:
+        pytest.skip("no iteration KAT")
+    K, d = g["it_cb_in"].shape
+    if not eng.prune_supported(K, d):
+        pytest.skip("shape not served by the pruned search")
+    srt, nd = eng.sort_image(dev(g["img"]), int(g["bh"]), int(g["bw"]))
+    acc, dist, labels = eng.lbg_accum(None, dev(g["it_cb_in"]), want_labels=True, sorted=srt, shape=nd)
+    assert np.array_equal(labels.cpu().numpy().astype(np.int64), g["it_labels"])
+    assert dist.item() / nd[0] == float(g["it_distortion"])
+    assert np.array_equal(eng.lbg_finalize(acc, dev(g["it_cb_in"])).cpu().numpy(), g["it_cb_out"])
+
+
+def test_full_size_image_fused_encode(eng):
+    """8192 x 8192: labels from the image in one call equal labels from extract + sort + search."""
+    from vector_quantization_amd import train_lbg
+    img = _structured(8192, 8192, 3)
+    blocks = eng.blocks_from_image(img, 4, 4)
+    cb = train_lbg(eng, eng.blocks_from_image(img[:1024, :1024].contiguous(), 4, 4), 256, log=None).codebook
+    want, want_d = eng.encode(blocks, cb, mode=1, sorted=eng.sort_blocks(blocks), want_dist=True)
+    got, got_d = eng.encode_image(img, 4, 4, cb, want_dist=True)
+    assert torch.equal(got, want) and torch.equal(got_d, want_d)
+    assert torch.equal(got, eng.encode(blocks, cb, mode=0))

@@ -20,7 +20,7 @@ VQ_MODE_FAST = 1
 VQ_PAD_EDGE = 0
 VQ_PAD_ZERO = 1
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -42,7 +42,11 @@ SIGNATURES = {
     "vq_sorted_bytes": (_sz, [_i, _i64]),
     "vq_prune_supported": (_i, [_i, _i]),
     "vq_blocks_sort": (_i, [_vp, _i64, _i, _vp, _sz, _vp]),
+    "vq_blocks_sort_img": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "vq_encode_l1_img": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "vq_encode_l1_prepared": (_i, [_vp, _vp, _sz, _i64, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "vq_encode_l1_prepared_phases": (_i, [_vp, _vp, _sz, _i64, _i, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp]),
+    "vq_workspace_counters_offset": (_sz, [_i, _i, _i64]),
     "vq_lbg_accum": (_i, [_vp, _vp, _sz, _i64, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "vq_numpy_sum_f64": (_i, [_vp, _i64, _vp, _vp, _vp]),
     "vq_accum_labels": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp, _vp]),

@@ -74,9 +74,12 @@ class Codebook:
         self.n_rows = self.padded_h // self.block_h
         self.n_cols = self.padded_w // self.block_w
 
-        # padding and block extraction are one kernel; the (N, d) matrix stays on the device
-        img_dev = torch.from_numpy(np.ascontiguousarray(self.img_arr)).to(self._engine.device)
-        self._blocks_dev = self._engine.blocks_from_image(img_dev, block_h, block_w, pad_mode)
+        # the image goes to the device once; the (N, d) block matrix (padding and extraction are one
+        # kernel) and its window-sorted second layout are built from it on first use
+        self._img_dev = torch.from_numpy(np.ascontiguousarray(self.img_arr)).to(self._engine.device)
+        self._n_vectors = self.n_rows * self.n_cols
+        self._dim = block_h * block_w * self.channels
+        self._blocks_dev_cache = None
         self._blocks_host = None
         self._blocks_sorted = None
         self._img_padded = None
@@ -92,6 +95,13 @@ class Codebook:
         self.reconstructed_path = os.path.join(out_dir, f"{self.base_name}_reconstructed.png")
 
     # -- attributes the reference materialises eagerly; fetched from the device on first use --------
+    @property
+    def _blocks_dev(self):
+        if self._blocks_dev_cache is None:
+            self._blocks_dev_cache = self._engine.blocks_from_image(self._img_dev, self.block_h, self.block_w,
+                                                                    self._pad_mode)
+        return self._blocks_dev_cache
+
     @property
     def blocks(self):
         """(N, d) uint8 block matrix (VQ_Full.py:37, :51-57)."""
@@ -129,12 +139,16 @@ class Codebook:
         """Second device layout of the block matrix (windows sorted by element sum) that lets the
         search skip codewords; built on first use, shared by training and compress."""
         if self._blocks_sorted is None:
-            self._blocks_sorted = self._engine.sort_blocks(self._blocks_dev)
+            if hasattr(self._engine, "sort_image"):           # image -> sorted rows in one pass
+                self._blocks_sorted, _ = self._engine.sort_image(self._img_dev, self.block_h, self.block_w,
+                                                                 self._pad_mode)
+            else:
+                self._blocks_sorted = self._engine.sort_blocks(self._blocks_dev)
         return self._blocks_sorted
 
     # -- training (VQ_Full.py:60-117) -------------------------------------------------------------------
     def generate_codebook(self, k, epsilon=0.01, threshold=0.001, max_iterations=100, *, iters_per_stage=None):
-        n_local = self._blocks_dev.shape[0]
+        n_local = self._n_vectors
         if self._group is None and k > n_local:
             raise ValueError(
                 f"Invalid quantization level k={k}: cannot exceed the total number of image blocks ({n_local})."
@@ -169,15 +183,21 @@ class Codebook:
         if self.codebook is None:
             raise ValueError("No codebook yet.")
         host = np.ascontiguousarray(self.codebook, dtype=np.float64)
-        if host.ndim != 2 or host.shape[1] != self._blocks_dev.shape[1]:
-            raise ValueError(f"codebook must be (K, {self._blocks_dev.shape[1]}), got {host.shape}")
+        if host.ndim != 2 or host.shape[1] != self._dim:
+            raise ValueError(f"codebook must be (K, {self._dim}), got {host.shape}")
         if (self._codebook_dev is None or self._codebook_dev_src is None
                 or self._codebook_dev_src.shape != host.shape
                 or not np.array_equal(self._codebook_dev_src.view(np.uint64), host.view(np.uint64))):
             # assigned or edited by the caller since the device copy was made
             self._codebook_dev = torch.from_numpy(host).to(self._engine.device)
             self._codebook_dev_src = host.copy()
-        labels_dev = self._engine.encode(self._blocks_dev, self._codebook_dev, sorted=self._sorted_blocks())
+        srt = self._sorted_blocks()
+        if (srt is not None and self._blocks_dev_cache is None and hasattr(self._engine, "sort_image")
+                and self._engine.prune_supported(host.shape[0], self._dim) and getattr(self._engine, "mode", 1) == 1):
+            # the search runs on the sorted rows made straight from the image: no block matrix at all
+            labels_dev = self._engine.encode(None, self._codebook_dev, sorted=srt, shape=(self._n_vectors, self._dim))
+        else:
+            labels_dev = self._engine.encode(self._blocks_dev, self._codebook_dev, sorted=srt)
         self._labels_dev = labels_dev
         labels_grid = labels_dev.cpu().numpy().astype(np.int64).reshape(self.n_rows, self.n_cols)
 

@@ -76,7 +76,7 @@ int fail(int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(VQ_E_HIP, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
     } while (0)
 
-constexpr int ABI_VERSION = 3;
+constexpr int ABI_VERSION = 4;
 constexpr int WAVE = 64;
 constexpr int64_t NP_CHUNK = 8192;      // numpy's reduction buffer: elements per pairwise-summed chunk
 constexpr int MAX_D_FAST = 192;         // largest vector dimension of the SAD filter kernels
@@ -608,6 +608,82 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
 }
 
 // ------------------------------------------------------------------------------------------------
+// where the window sort takes its vectors from
+// ------------------------------------------------------------------------------------------------
+// The (N, d) block matrix in memory.
+struct SrcBlocks {
+    const uint8_t *p;
+    int d;
+    __device__ __forceinline__ uint32_t byte(int64_t n, int e) const { return p[(size_t)n * d + e]; }
+    // word w of vector n (rows are whole aligned words)
+    __device__ __forceinline__ uint32_t word(int64_t n, int w) const {
+        return reinterpret_cast<const uint32_t *>(p + (size_t)n * d)[w];
+    }
+    // DW aligned words of vector n (d = 4 * DW)
+    template <int DW>
+    __device__ __forceinline__ void row_words(int64_t n, uint32_t (&w)[DW]) const {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(p) + (size_t)n * DW;
+        if (DW == 4) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(src);
+            w[0] = v.x; w[1 % DW] = v.y; w[2 % DW] = v.z; w[3 % DW] = v.w;
+        } else if (DW == 2) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(src);
+            w[0] = v.x; w[1 % DW] = v.y;
+        } else {
+#pragma unroll
+            for (int i = 0; i < DW; ++i) w[i] = src[i];
+        }
+    }
+};
+
+// The image itself: vector n is block (n / nc, n % nc) of the image padded on the bottom / right to
+// multiples of (bh, bw), element e = (i * bw + j) * C + ch (VQ_Full.py:23-33, 51-57); nothing is
+// materialised, padding is resolved by clamping (edge) or zeroing the coordinate.
+struct SrcImage {
+    const uint8_t *img;
+    int H, W, C, bh, bw, pad_zero;
+    uint32_t nc, seg, d;          // blocks per block row, bytes per block row segment (bw * C), bh * seg
+    int words_ok;                 // image rows are whole aligned words (W * C % 4 == 0, base aligned)
+    __device__ __forceinline__ uint32_t byte_at(uint32_t r, uint32_t q, uint32_t e) const {
+        const uint32_t i = e / seg, rem = e - i * seg;
+        const uint32_t j = rem / (uint32_t)C, ch = rem - j * (uint32_t)C;
+        const int y = (int)(r * (uint32_t)bh + i), x = (int)(q * (uint32_t)bw + j);
+        const int yc = y < H ? y : H - 1, xc = x < W ? x : W - 1;
+        uint32_t v = img[((size_t)yc * W + xc) * C + ch];
+        if (pad_zero && (y >= H || x >= W)) v = 0;
+        return v;
+    }
+    __device__ __forceinline__ uint32_t byte(int64_t n, int e) const {
+        const uint32_t r = (uint32_t)n / nc, q = (uint32_t)n - r * nc;
+        return byte_at(r, q, (uint32_t)e);
+    }
+    // bytes e .. e + 3 of block (r, q) as one word
+    __device__ __forceinline__ uint32_t word_at(uint32_t r, uint32_t q, uint32_t e) const {
+        const uint32_t i = e / seg, rem = e - i * seg;
+        const int y = (int)(r * (uint32_t)bh + i);
+        const int yc = y < H ? y : H - 1;
+        const int64_t rowbytes = (int64_t)W * C;
+        const int64_t xb = (int64_t)q * seg + rem;           // byte offset inside the (padded) image row
+        if (words_ok && (seg & 3u) == 0 && xb + 4 <= rowbytes && (y < H || !pad_zero))
+            return *reinterpret_cast<const uint32_t *>(img + (size_t)yc * rowbytes + xb);
+        uint32_t v = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v |= byte_at(r, q, e + t) << (8 * t);
+        return v;
+    }
+    __device__ __forceinline__ uint32_t word(int64_t n, int w) const {
+        const uint32_t r = (uint32_t)n / nc, q = (uint32_t)n - r * nc;
+        return word_at(r, q, 4u * (uint32_t)w);
+    }
+    template <int DW>
+    __device__ __forceinline__ void row_words(int64_t n, uint32_t (&w)[DW]) const {
+        const uint32_t r = (uint32_t)n / nc, q = (uint32_t)n - r * nc;
+#pragma unroll
+        for (int k = 0; k < DW; ++k) w[k] = word_at(r, q, 4u * k);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
 // windowed sort of the block vectors by element sum (input of the pruned search)
 // ------------------------------------------------------------------------------------------------
 // One workgroup per window of SORT_WIN vectors: a counting sort on the element sum (bucketed) places
@@ -615,9 +691,14 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
 // `perm` (position inside the window).  Vectors never leave their window, so everything the search
 // later writes per vector (label, distance) lands within 32 / 64 KB of its neighbours.  The order
 // inside a bucket depends on the order the atomics retire in; nothing computed from the sorted copy
-// depends on it.  This kernel serves rows of any length and alignment, byte by byte; rows of one to
-// four aligned words take k_window_sort_lds.
-__global__ __launch_bounds__(1024) void k_window_sort(const uint8_t *__restrict__ blocks, int64_t N, int d, int bshift,
+// depends on it.  This kernel serves rows of any length: every thread sums its vectors and takes their
+// ranks, the inverse map (sorted slot -> origin) goes to LDS, and then the whole workgroup copies the
+// window in OUTPUT order -- consecutive lanes write consecutive words (WORDS: d % 4 == 0 and the source
+// delivers aligned words) or bytes of consecutive sorted rows, so the stores are coalesced and the source
+// rows, just read for their sums, come from the cache.  Rows of one to four words take
+// k_window_sort_lds instead.
+template <class SRC, bool WORDS>
+__global__ __launch_bounds__(1024) void k_window_sort(const SRC src, int64_t N, int d, int bshift,
                                                       uint8_t *__restrict__ rows, uint16_t *__restrict__ perm,
                                                       SortedHeader *__restrict__ shdr) {
     constexpr int T = 1024;
@@ -629,20 +710,26 @@ __global__ __launch_bounds__(1024) void k_window_sort(const uint8_t *__restrict_
     constexpr int PER = SORT_WIN / T;                       // vectors per thread
     __shared__ uint32_t s_cnt[SORT_BUCKETS];
     __shared__ uint32_t s_wsum[T / WAVE];
+    __shared__ uint16_t s_inv[SORT_WIN];                    // sorted slot -> position in the window it came from
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
     const int64_t w0 = (int64_t)blockIdx.x * SORT_WIN;
+    const int count = (int)((N - w0) < SORT_WIN ? (N - w0) : SORT_WIN);      // vectors in this window
     for (int i = tid; i < SORT_BUCKETS; i += T) s_cnt[i] = 0u;
     __syncthreads();
     uint32_t bucket[PER], rank[PER];
+    const int dw = d >> 2;
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
-        const int64_t n = w0 + (int64_t)j * T + tid;
-        bucket[j] = 0xffffffffu;
+        const int li = j * T + tid;
+        bucket[j] = 0;
         rank[j] = 0;
-        if (n < N) {
+        if (li < count) {
             uint32_t sum = 0;
-            const uint8_t *row = blocks + (size_t)n * d;
-            for (int e = 0; e < d; ++e) sum += row[e];
+            if (WORDS) {
+                for (int w = 0; w < dw; ++w) sum = __builtin_amdgcn_sad_u8(src.word(w0 + li, w), 0u, sum);
+            } else {
+                for (int e = 0; e < d; ++e) sum += src.byte(w0 + li, e);
+            }
             bucket[j] = sum >> bshift;
             rank[j] = atomicAdd(&s_cnt[bucket[j]], 1u);
         }
@@ -668,13 +755,23 @@ __global__ __launch_bounds__(1024) void k_window_sort(const uint8_t *__restrict_
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         const int li = j * T + tid;
-        const int64_t n = w0 + li;
-        if (n < N) {
-            const int64_t slot = w0 + (int64_t)(s_cnt[bucket[j]] + rank[j]);
-            const uint8_t *src = blocks + (size_t)n * d;
-            uint8_t *dst = rows + (size_t)slot * d;
-            for (int e = 0; e < d; ++e) dst[e] = src[e];
-            perm[slot] = (uint16_t)li;
+        if (li < count) s_inv[s_cnt[bucket[j]] + rank[j]] = (uint16_t)li;          // slot < count
+    }
+    __syncthreads();
+    for (int i = tid; i < count; i += T) perm[w0 + i] = s_inv[i];
+    if (WORDS) {
+        uint32_t *out = reinterpret_cast<uint32_t *>(rows) + (size_t)w0 * dw;
+        const int total = count * dw;
+        for (int i = tid; i < total; i += T) {
+            const int slot = i / dw, w = i - slot * dw;
+            out[i] = src.word(w0 + (int64_t)s_inv[slot], w);
+        }
+    } else {
+        uint8_t *out = rows + (size_t)w0 * d;
+        const int total = count * d;
+        for (int i = tid; i < total; i += T) {
+            const int slot = i / d, e = i - slot * d;
+            out[i] = (uint8_t)src.byte(w0 + (int64_t)s_inv[slot], e);
         }
     }
 }
@@ -683,8 +780,8 @@ __global__ __launch_bounds__(1024) void k_window_sort(const uint8_t *__restrict_
 // placed at their sorted positions in LDS (8192 * d bytes) and written out in order, so that every
 // global access of the kernel is coalesced (a scattered store costs one L2 request per lane).
 // Dynamic LDS: [SORT_WIN * DW words of rows][SORT_WIN uint16 origins].
-template <int DW>
-__global__ __launch_bounds__(1024) void k_window_sort_lds(const uint32_t *__restrict__ blocks, int64_t N, int bshift,
+template <int DW, class SRC>
+__global__ __launch_bounds__(1024) void k_window_sort_lds(const SRC src, int64_t N, int bshift,
                                                           uint32_t *__restrict__ rows, uint16_t *__restrict__ perm,
                                                           SortedHeader *__restrict__ shdr) {
     constexpr int T = 1024;
@@ -709,17 +806,7 @@ __global__ __launch_bounds__(1024) void k_window_sort_lds(const uint32_t *__rest
     for (int j = 0; j < PER; ++j) {
         const int li = j * T + tid;
         const int lc = li < count ? li : count - 1;         // clamped: loads stay in bounds
-        const uint32_t *src = blocks + (size_t)(w0 + lc) * DW;
-        if (DW == 4) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(src);
-            keep[j][0] = v.x; keep[j][1 % DW] = v.y; keep[j][2 % DW] = v.z; keep[j][3 % DW] = v.w;
-        } else if (DW == 2) {
-            const uint2 v = *reinterpret_cast<const uint2 *>(src);
-            keep[j][0] = v.x; keep[j][1 % DW] = v.y;
-        } else {
-#pragma unroll
-            for (int w = 0; w < DW; ++w) keep[j][w] = src[w];
-        }
+        src.template row_words<DW>(w0 + lc, keep[j]);
     }
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
@@ -789,8 +876,10 @@ struct AssignArgs {
     const PrepHeader *hdr;
     int32_t *labels;            // N; written for unambiguous vectors only
     double *min_dist;           // nullable; written for unambiguous vectors only
-    uint32_t *queue;            // NQ sub-queues of qcap entries: indices of ambiguous vectors, in no particular order
-    uint32_t *qcount;           // entries per sub-queue, counter q at qcount[16 * q] (zeroed before the launch)
+    uint32_t *queue;            // NQ sub-queues of qcap entries: ambiguous vectors, in no particular order (their
+                                // index in `blocks`, or with PRUNE their position in the sorted copy)
+    uint32_t *qcount;           // entries per sub-queue, counter q at qcount[16 * q] (zeroed before the launch);
+                                // the 64-bit word at qcount[16 * q + 2] collects the pairs evaluated (statistics)
     uint32_t qcap;
     unsigned long long *acc_rep; // ACC: NREP replicas of the [K][d+1] table of [sums | count], zeroed before the launch
     int vec4;                   // 1: rows may be read as aligned 32-bit words (d % 4 == 0, base 4-byte aligned);
@@ -935,6 +1024,7 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
             }
         }
         // ---- filter: two smallest keys per vector ----
+        uint32_t rows_searched = 0;                            // codebook rows this wave evaluated (wave-uniform)
         uint32_t m1[R], m2[R], bi[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -990,6 +1080,7 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
             const int kpad = (K + 7) & ~7;
             if constexpr (!PRUNE) {
                 run(0, (K + U - 1) / U * U);
+                rows_searched = (uint32_t)((K + U - 1) / U * U);
             } else {
                 // wave-uniform range of the vectors' element sums (same fixed-point units as the rows)
                 uint32_t sxlo = 0xffffffffu, sxhi = 0u;
@@ -1034,6 +1125,7 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
                     pa = na;
                     pb = nb;
                 }
+                rows_searched = (uint32_t)(pb - pa);
             }
         } else {
             constexpr int TILE_K = tile_k_for(DP2);
@@ -1127,7 +1219,13 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
                 if (t + 1 < ntk) lstore(t + 1);
                 __syncthreads();
             }
+            rows_searched = (uint32_t)(ntk * TILE_K);
         }
+        // statistics: (vector, codeword) pairs this wave evaluated, summed into the 64-bit word at byte 8 of
+        // the wave's sub-queue slot
+        if (lane == 0)
+            atomicAdd(reinterpret_cast<unsigned long long *>(a.qcount + 16 * ((uint32_t)(vec_index(0) >> 6) & (NQ - 1)) + 2),
+                      (unsigned long long)rows_searched * (unsigned long long)(WAVE * R));
         // ---- decide, measure, write, accumulate ----
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -1161,7 +1259,8 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
                 if (lane == leader) qbase = atomicAdd(a.qcount + 16 * q, (uint32_t)__popcll(amask));
                 qbase = __builtin_amdgcn_readlane(qbase, leader);
                 if (amb)
-                    a.queue[(size_t)q * a.qcap + qbase + (uint32_t)__popcll(amask & ((1ull << lane) - 1ull))] = (uint32_t)n;
+                    a.queue[(size_t)q * a.qcap + qbase + (uint32_t)__popcll(amask & ((1ull << lane) - 1ull))] =
+                        PRUNE ? (uint32_t)ns : (uint32_t)n;       // pruned: position in the sorted copy
             }
             const bool settled = valid && !amb;
             if constexpr (ACC) {
@@ -1255,8 +1354,8 @@ __global__ __launch_bounds__(256) void k_reduce_replicas(const unsigned long lon
 // A wave fetches the queue entries and vector rows of four items at once (two memory round trips
 // per four items); with LDS_CB the transposed codebook is staged in LDS once per workgroup.
 template <bool LDS_CB>
-__global__ __launch_bounds__(1024) void k_fixup(const uint8_t *__restrict__ blocks, int d,
-                                                const double *__restrict__ cbT, int K,
+__global__ __launch_bounds__(1024) void k_fixup(const uint8_t *__restrict__ blocks, const uint16_t *__restrict__ perm,
+                                                int64_t N, int d, const double *__restrict__ cbT, int K,
                                                 const uint32_t *__restrict__ queue,
                                                 const uint32_t *__restrict__ qcount, uint32_t qcap,
                                                 int32_t *__restrict__ labels, double *__restrict__ min_dist,
@@ -1286,12 +1385,21 @@ __global__ __launch_bounds__(1024) void k_fixup(const uint8_t *__restrict__ bloc
     const uint32_t count = qcount[16 * sub];
     queue += (size_t)sub * qcap;
     for (uint32_t i0 = rank; i0 < count; i0 += 4 * nwaves) {
-        int64_t n[4];
+        int64_t n[4], m[4];                                    // row to read; vector index to write
         uint32_t xv[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const uint32_t i = i0 + t * nwaves;
             n[t] = (int64_t)queue[i < count ? i : count - 1];  // wave-uniform
+            n[t] = n[t] < N ? n[t] : N - 1;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            m[t] = n[t];
+            if (perm) {                                        // `blocks` is the sorted copy: origin inside the window
+                m[t] = (n[t] & ~(int64_t)(SORT_WIN - 1)) + (int64_t)perm[n[t]];
+                m[t] = m[t] < N ? m[t] : N - 1;
+            }
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) xv[t] = lane < d ? (uint32_t)blocks[(size_t)n[t] * d + lane] : 0u;
@@ -1303,8 +1411,8 @@ __global__ __launch_bounds__(1024) void k_fixup(const uint8_t *__restrict__ bloc
             double rd;
             exact_search_wave<LDS_CB>(xv[t], xrow, d, cbT, s_cbT, K, lane, ri, rd);
             if (lane == 0) {
-                labels[n[t]] = ri;
-                if (min_dist) min_dist[n[t]] = rd;
+                labels[m[t]] = ri;
+                if (min_dist) min_dist[m[t]] = rd;
             }
             if (sums) {
                 for (int e = lane; e < d; e += WAVE) {
@@ -1326,7 +1434,8 @@ __global__ __launch_bounds__(1024) void k_fixup(const uint8_t *__restrict__ bloc
 // whichever side is not covered yet.  A skipped codeword is strictly further away than the winner,
 // so label and distance equal those of the full search, ties included (lowest codeword index).
 template <bool LDS_CB>
-__global__ __launch_bounds__(1024) void k_fixup_pruned(const uint8_t *__restrict__ blocks, int d,
+__global__ __launch_bounds__(1024) void k_fixup_pruned(const uint8_t *__restrict__ blocks,
+                                                       const uint16_t *__restrict__ perm, int64_t N, int d,
                                                        const double *__restrict__ cbT, int K,
                                                        const uint32_t *__restrict__ queue,
                                                        const uint32_t *__restrict__ qcount, uint32_t qcap,
@@ -1360,8 +1469,14 @@ __global__ __launch_bounds__(1024) void k_fixup_pruned(const uint8_t *__restrict
     const uint32_t count = qcount[16 * sub];
     queue += (size_t)sub * qcap;
     for (uint32_t i0 = rank; i0 < count; i0 += nwaves) {
-        const int64_t n = (int64_t)queue[i0];                   // wave-uniform
-        const uint8_t *xrow = blocks + (size_t)n * d;
+        int64_t nrow = (int64_t)queue[i0];                      // wave-uniform
+        nrow = nrow < N ? nrow : N - 1;
+        int64_t n = nrow;                                       // vector index the results are written at
+        if (perm) {                                             // `blocks` is the sorted copy: origin inside the window
+            n = (nrow & ~(int64_t)(SORT_WIN - 1)) + (int64_t)perm[nrow];
+            n = n < N ? n : N - 1;
+        }
+        const uint8_t *xrow = blocks + (size_t)nrow * d;
         // element sum of the vector in the fixed-point units of the codebook rows
         uint32_t part = 0;
         for (int e = lane; e < d; e += WAVE) part += xrow[e];
@@ -1380,7 +1495,19 @@ __global__ __launch_bounds__(1024) void k_fixup_pruned(const uint8_t *__restrict
                 const int ecount = d - ebase < WAVE ? d - ebase : WAVE;
                 uint32_t xv = xv0;
                 if (ebase > 0) xv = lane < ecount ? (uint32_t)xrow[ebase + lane] : 0u;
-                for (int e0 = 0; e0 < ecount; ++e0) {
+                // loads eight elements ahead of the additions that use them (the additions stay in element order)
+                int e0 = 0;
+                for (; e0 + 8 <= ecount; e0 += 8) {
+                    double c[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const size_t off = (size_t)(ebase + e0 + j) * K + k;
+                        c[j] = LDS_CB ? s_cbT[off] : cbT[off];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc += fabs((double)__builtin_amdgcn_readlane(xv, e0 + j) - c[j]);
+                }
+                for (; e0 < ecount; ++e0) {
                     const size_t off = (size_t)(ebase + e0) * K + k;
                     const double xe = (double)__builtin_amdgcn_readlane(xv, e0);
                     acc += fabs(xe - (LDS_CB ? s_cbT[off] : cbT[off]));
@@ -1591,7 +1718,8 @@ __global__ __launch_bounds__(256) void k_assign_exact(const uint8_t *__restrict_
 // vectors per trip, lane (v, e) adds byte e of vector v to sums[label_v * d + e], so that one
 // wave-instruction adds to runs of d consecutive 64-bit words.  Serves vq_accum_labels and the
 // codebooks whose [K][d+1] table does not fit the LDS.
-__global__ __launch_bounds__(256) void k_accum_rows(const uint8_t *__restrict__ blocks, int64_t N, int d,
+__global__ __launch_bounds__(256) void k_accum_rows(const uint8_t *__restrict__ blocks,
+                                                    const uint16_t *__restrict__ perm, int64_t N, int d,
                                                     const int32_t *__restrict__ labels, int K,
                                                     unsigned long long *__restrict__ sums,
                                                     unsigned long long *__restrict__ counts) {
@@ -1605,7 +1733,12 @@ __global__ __launch_bounds__(256) void k_accum_rows(const uint8_t *__restrict__ 
     for (int64_t n0 = wave * V; n0 < N; n0 += nwaves * V) {
         const int64_t n = n0 + v;
         if (!lane_on || n >= N) continue;
-        const int k = labels[n];
+        int64_t m = n;                                       // index of row n's vector in the caller's order
+        if (perm) {
+            m = (n & ~(int64_t)(SORT_WIN - 1)) + (int64_t)perm[n];
+            m = m < N ? m : N - 1;
+        }
+        const int k = labels[m];
         if ((unsigned)k >= (unsigned)K) continue;
         const uint8_t *x = blocks + (size_t)n * d;
         for (int e = e0; e < d; e += WAVE) {
@@ -1623,7 +1756,8 @@ __global__ __launch_bounds__(256) void k_accum_rows(const uint8_t *__restrict__ 
 // evaluates sum_e |x_e - cb[label][e]| in sequential fp64 (the value VQ_Full.py:89 gathers) for
 // every vector; CB_LDS stages the fp64 codebook in LDS behind the table.  VEC16: 16-byte rows.
 template <bool VEC16, bool CB_LDS>
-__global__ __launch_bounds__(512) void k_accum_dist(const uint8_t *__restrict__ blocks, int64_t N, int d,
+__global__ __launch_bounds__(512) void k_accum_dist(const uint8_t *__restrict__ blocks,
+                                                    const uint16_t *__restrict__ perm, int64_t N, int d,
                                                     const int32_t *__restrict__ labels,
                                                     const double *__restrict__ cb, int K,
                                                     unsigned long long *__restrict__ sums,
@@ -1656,16 +1790,22 @@ __global__ __launch_bounds__(512) void k_accum_dist(const uint8_t *__restrict__ 
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     uint32_t trips = 0;
     for (int64_t n0 = (int64_t)blockIdx.x * blockDim.x; n0 < N; n0 += UV * stride) {
-        int64_t n[UV];
+        int64_t n[UV], m[UV];                                    // row read; vector index in the caller's order
         int k[UV];
         uint4 v[UV];
 #pragma unroll
         for (int u = 0; u < UV; ++u) {
             n[u] = n0 + u * stride + tid;
             const int64_t nc = n[u] < N ? n[u] : N - 1;           // clamped: loads stay in bounds
-            k[u] = labels[nc];
+            m[u] = nc;
+            if (perm) {                                           // `blocks` is the sorted copy
+                m[u] = (nc & ~(int64_t)(SORT_WIN - 1)) + (int64_t)perm[nc];
+                m[u] = m[u] < N ? m[u] : N - 1;
+            }
             if (VEC16) v[u] = reinterpret_cast<const uint4 *>(blocks)[nc];
         }
+#pragma unroll
+        for (int u = 0; u < UV; ++u) k[u] = labels[m[u]];
 #pragma unroll
         for (int u = 0; u < UV; ++u) {
             if (n[u] >= N || (unsigned)k[u] >= (unsigned)K) continue;
@@ -1689,7 +1829,7 @@ __global__ __launch_bounds__(512) void k_accum_dist(const uint8_t *__restrict__ 
                 }
             }
             atomicAdd(&t[d], 1u);
-            if (min_dist) min_dist[n[u]] = acc;
+            if (min_dist) min_dist[m[u]] = acc;
         }
         // 32-bit LDS sums grow by at most 255 * UV * blockDim per trip: flush long before they can wrap
         if ((++trips & 0x3fffu) == 0) {
@@ -1988,8 +2128,10 @@ KeyLayout key_layout(int K, int dp2) {
     return kl;
 }
 
-int check_common(const void *blocks, int64_t N, int d, const void *cb, int K) {
-    if ((!blocks && N != 0) || !cb) return fail(VQ_E_INVALID, "null blocks or codebook pointer");
+// blocks_optional: the call has a window-sorted copy that serves this (K, d), so the block matrix itself is
+// not needed
+int check_common(const void *blocks, int64_t N, int d, const void *cb, int K, bool blocks_optional = false) {
+    if ((!blocks && N != 0 && !blocks_optional) || !cb) return fail(VQ_E_INVALID, "null blocks or codebook pointer");
     if (N < 0 || d <= 0 || K <= 0) return fail(VQ_E_INVALID, "need N >= 0, d > 0, K > 0 (got N=%lld d=%d K=%d)", (long long)N, d, K);
     if (K > MAX_K) return fail(VQ_E_UNSUPPORTED, "K=%d exceeds %d", K, MAX_K);
     return VQ_OK;
@@ -2096,7 +2238,7 @@ bool fused_acc_supported(const void *sorted, int K, int d) {
 // sums / counts non-null (only with fused_acc_supported): cluster sums are accumulated too.
 int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d, const double *cb, int K,
              int32_t *labels, double *min_dist, unsigned long long *sums, unsigned long long *counts, void *ws,
-             hipStream_t st) {
+             hipStream_t st, int phases = 3) {
     const int dp2 = dp2_bucket(d);
     if (sorted != nullptr && prune_supported(K, d)) {          // before any work is enqueued
         int src = sorted_check(sorted, sorted_bytes, N, d);
@@ -2111,7 +2253,8 @@ int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int
     WsLayout LN = ws_layout(K, d, N);
     uint32_t *qcount = reinterpret_cast<uint32_t *>(w + LN.qcount);
     uint32_t *queue = reinterpret_cast<uint32_t *>(w + LN.queue);
-    HIP_TRY(hipMemsetAsync(qcount, 0, (size_t)NQ * 64, st));
+    const bool do_filter = (phases & 1) != 0, do_fixup = (phases & 2) != 0;
+    if (do_filter) HIP_TRY(hipMemsetAsync(qcount, 0, (size_t)NQ * 64, st));
     const uint32_t qcap = (uint32_t)queue_cap(N);
 
     DeviceInfo di;
@@ -2159,6 +2302,7 @@ int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int
         if (SORT_WIN % tile != 0) return fail(VQ_E_HIP, "internal: sort window %d is not a multiple of the tile %lld", SORT_WIN, (long long)tile);
     }
 
+    if (do_filter)
     switch (dp2) {
         case 2:  rc = launch_assign_fast_k<2>(a, c16, bias, packed, lds_cw, prune, block, grid, lds, st); break;
         case 4:  rc = launch_assign_fast_k<4>(a, c16, bias, packed, lds_cw, prune, block, grid, lds, st); break;
@@ -2174,6 +2318,10 @@ int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int
         default: return fail(VQ_E_UNSUPPORTED, "no fast kernel for d=%d", d);
     }
     if (rc) return rc;
+    if (!do_fixup) return VQ_OK;
+    // the fix-up reads the rows the queue entries point at: the sorted copy after a pruned search
+    const uint8_t *fx_rows = prune ? a.rows : blocks;
+    const uint16_t *fx_perm = prune ? a.perm : nullptr;
     // fix-up: a fixed grid strides over the sub-queues (their lengths are only known on the device);
     // small codebooks are staged in LDS, one 1024-thread workgroup per CU
     const size_t cb_bytes = (size_t)K * d * sizeof(double);
@@ -2181,26 +2329,26 @@ int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int
     // ones are cheaper to scan whole with four queue items in flight per wave.
     if (K >= VQ_FIXUP_PRUNE_MIN_K && K <= PREP_SORT_CAP) {
         const uint32_t *postab = reinterpret_cast<const uint32_t *>(w + L.postab);
-        if (cb_bytes <= 64 * 1024) {
+        if (cb_bytes <= 128 * 1024) {
             if (cb_bytes > 48 * 1024)
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fixup_pruned<true>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)cb_bytes));
-            hipLaunchKernelGGL(k_fixup_pruned<true>, dim3((di.cus + 3) / 4 * 4), dim3(1024), cb_bytes, st, blocks, d, cbT, K,
-                               queue, qcount, qcap, hdr, bias, postab, labels, min_dist, sums, counts);
+            hipLaunchKernelGGL(k_fixup_pruned<true>, dim3((di.cus + 3) / 4 * 4), dim3(1024), cb_bytes, st, fx_rows, fx_perm, N, d,
+                               cbT, K, queue, qcount, qcap, hdr, bias, postab, labels, min_dist, sums, counts);
         } else {
-            hipLaunchKernelGGL(k_fixup_pruned<false>, dim3((di.cus * 4 + 15) / 16 * 16), dim3(256), 0, st, blocks, d, cbT, K,
-                               queue, qcount, qcap, hdr, bias, postab, labels, min_dist, sums, counts);
+            hipLaunchKernelGGL(k_fixup_pruned<false>, dim3((di.cus * 4 + 15) / 16 * 16), dim3(256), 0, st, fx_rows, fx_perm, N, d,
+                               cbT, K, queue, qcount, qcap, hdr, bias, postab, labels, min_dist, sums, counts);
         }
         LAUNCH_CHECK("k_fixup_pruned");
     } else if (cb_bytes <= 64 * 1024) {
         if (cb_bytes > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fixup<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)cb_bytes));
-        hipLaunchKernelGGL(k_fixup<true>, dim3((di.cus + 3) / 4 * 4), dim3(1024), cb_bytes, st, blocks, d, cbT, K, queue,
-                           qcount, qcap, labels, min_dist, sums, counts);
+        hipLaunchKernelGGL(k_fixup<true>, dim3((di.cus + 3) / 4 * 4), dim3(1024), cb_bytes, st, fx_rows, fx_perm, N, d, cbT,
+                           K, queue, qcount, qcap, labels, min_dist, sums, counts);
     } else {
-        hipLaunchKernelGGL(k_fixup<false>, dim3((di.cus * 4 + 15) / 16 * 16), dim3(256), 0, st, blocks, d, cbT, K, queue,
-                           qcount, qcap, labels, min_dist, sums, counts);
+        hipLaunchKernelGGL(k_fixup<false>, dim3((di.cus * 4 + 15) / 16 * 16), dim3(256), 0, st, fx_rows, fx_perm, N, d, cbT, K,
+                           queue, qcount, qcap, labels, min_dist, sums, counts);
     }
     LAUNCH_CHECK("k_fixup");
     if (sums) {
@@ -2217,8 +2365,8 @@ bool accum_table_fits(int K, int d, const DeviceInfo &di) { return (size_t)K * (
 // Per-cluster sums / counts for a finished labelling, plus (want_dist) the fp64 distance of every
 // vector to its codeword: the LDS-table kernel when the table fits, else coalesced global atomics.
 // When the table does not fit, distances are NOT computed here (the caller asks the search for them).
-int run_accum(const uint8_t *blocks, int64_t N, int d, const int32_t *labels, const double *cb, int K,
-              unsigned long long *sums, unsigned long long *counts, double *min_dist, hipStream_t st) {
+int run_accum(const uint8_t *blocks, const uint16_t *perm, int64_t N, int d, const int32_t *labels, const double *cb,
+              int K, unsigned long long *sums, unsigned long long *counts, double *min_dist, hipStream_t st) {
     DeviceInfo di;
     int rc = device_info(di);
     if (rc) return rc;
@@ -2239,7 +2387,7 @@ int run_accum(const uint8_t *blocks, int64_t N, int d, const int32_t *labels, co
         if (lds > 48 * 1024)                                                                                           \
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                          \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(ACC_BLOCK), lds, st, blocks, N, d, labels, cb, K, sums, counts, min_dist); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(ACC_BLOCK), lds, st, blocks, perm, N, d, labels, cb, K, sums, counts, min_dist); \
     } while (0)
         if (vec16 && cb_lds) VQ_LAUNCH_ACCUM(true, true);
         else if (vec16) VQ_LAUNCH_ACCUM(true, false);
@@ -2250,8 +2398,8 @@ int run_accum(const uint8_t *blocks, int64_t N, int d, const int32_t *labels, co
         return VQ_OK;
     }
     const int V = d >= WAVE ? 1 : WAVE / d;
-    hipLaunchKernelGGL(k_accum_rows, dim3(grid_for((N + V - 1) / V, 4, 16384)), dim3(256), 0, st, blocks, N, d, labels, K,
-                       sums, counts);
+    hipLaunchKernelGGL(k_accum_rows, dim3(grid_for((N + V - 1) / V, 4, 16384)), dim3(256), 0, st, blocks, perm, N, d, labels,
+                       K, sums, counts);
     LAUNCH_CHECK("k_accum_rows");
     return VQ_OK;
 }
@@ -2269,6 +2417,56 @@ int run_numpy_sum(const double *v, int64_t N, double *chunk_sums, double *out, h
     }
     hipLaunchKernelGGL(k_npsum_final, dim3(1), dim3(1024), 0, st, v, N, nfull, chunk_sums, out);
     LAUNCH_CHECK("k_npsum_final");
+    return VQ_OK;
+}
+
+// Fills `sorted` (rows, origins, header) from a vector source.  row_words_ok: rows are whole words the
+// source can deliver aligned; rows of one to four such words are staged in LDS and leave in order.
+template <class SRC>
+int run_sort(const SRC &src, bool row_words_ok, int64_t N, int d, void *sorted, size_t sorted_bytes, hipStream_t st) {
+    const bool words = row_words_ok && d <= 16;
+    if (d > MAX_D_FAST) return fail(VQ_E_UNSUPPORTED, "d=%d is beyond the fast kernels", d);
+    if (N > 0xfffffff0LL) return fail(VQ_E_UNSUPPORTED, "N=%lld exceeds 2^32 per call", (long long)N);
+    if (!sorted) return fail(VQ_E_INVALID, "null pointer");
+    SortedLayout SL = sorted_layout(d, N);
+    if (sorted_bytes < SL.total) return fail(VQ_E_WORKSPACE, "sorted buffer of %zu bytes needed, %zu given", SL.total, sorted_bytes);
+    if (reinterpret_cast<uintptr_t>(sorted) & 15) return fail(VQ_E_INVALID, "sorted buffer must be 16-byte aligned");
+    char *sp = static_cast<char *>(sorted);
+    uint8_t *rows = reinterpret_cast<uint8_t *>(sp + SL.rows);
+    uint16_t *perm = reinterpret_cast<uint16_t *>(sp + SL.perm);
+    SortedHeader *shdr = reinterpret_cast<SortedHeader *>(sp + SL.hdr);
+    int bshift = 0;                                        // element sums 0 .. 255 * d into SORT_BUCKETS buckets
+    while (((255u * (uint32_t)d) >> bshift) >= (uint32_t)SORT_BUCKETS) ++bshift;
+    const int grid = (int)((N + SORT_WIN - 1) / SORT_WIN);
+    DeviceInfo di;
+    int rc = device_info(di);
+    if (rc) return rc;
+    const size_t lds_need = (size_t)SORT_WIN * d + (size_t)SORT_WIN * 2 + (SORT_BUCKETS + 16) * 4 + 256;
+    if (words && lds_need <= di.lds_per_block) {
+        const size_t lds = (size_t)SORT_WIN * d + (size_t)SORT_WIN * 2;
+        uint32_t *r32 = reinterpret_cast<uint32_t *>(rows);
+#define VQ_LAUNCH_SORT(DW)                                                                                          \
+    do {                                                                                                            \
+        auto kern = k_window_sort_lds<DW, SRC>;                                                                     \
+        if (lds > 48 * 1024)                                                                                        \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                       \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, st, src, N, bshift, r32, perm, shdr);                 \
+    } while (0)
+        switch (d / 4) {
+            case 1: VQ_LAUNCH_SORT(1); break;
+            case 2: VQ_LAUNCH_SORT(2); break;
+            case 3: VQ_LAUNCH_SORT(3); break;
+            default: VQ_LAUNCH_SORT(4); break;
+        }
+#undef VQ_LAUNCH_SORT
+    } else if (row_words_ok) {
+        hipLaunchKernelGGL((k_window_sort<SRC, true>), dim3(grid), dim3(1024), 0, st, src, N, d, bshift, rows, perm, shdr);
+    } else {
+        hipLaunchKernelGGL((k_window_sort<SRC, false>), dim3(grid), dim3(1024), 0, st, src, N, d, bshift, rows, perm, shdr);
+    }
+    LAUNCH_CHECK("k_window_sort");
+    sorted_register(sorted, N, d, sorted_bytes);
     return VQ_OK;
 }
 
@@ -2408,70 +2606,85 @@ int vq_prune_supported(int K, int d) { return (K > 0 && d > 0 && prune_supported
 
 int vq_blocks_sort(const uint8_t *blocks, int64_t N, int d, void *sorted, size_t sorted_bytes, void *stream) {
     if (N < 0 || d <= 0) return fail(VQ_E_INVALID, "need N >= 0 and d > 0");
-    if (d > MAX_D_FAST) return fail(VQ_E_UNSUPPORTED, "d=%d is beyond the fast kernels", d);
-    if (N > 0xfffffff0LL) return fail(VQ_E_UNSUPPORTED, "N=%lld exceeds 2^32 per call", (long long)N);
     if (N == 0) return VQ_OK;
-    if (!blocks || !sorted) return fail(VQ_E_INVALID, "null pointer");
-    SortedLayout SL = sorted_layout(d, N);
-    if (sorted_bytes < SL.total) return fail(VQ_E_WORKSPACE, "sorted buffer of %zu bytes needed, %zu given", SL.total, sorted_bytes);
-    if (reinterpret_cast<uintptr_t>(sorted) & 15) return fail(VQ_E_INVALID, "sorted buffer must be 16-byte aligned");
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    char *sp = static_cast<char *>(sorted);
-    uint8_t *rows = reinterpret_cast<uint8_t *>(sp + SL.rows);
-    uint16_t *perm = reinterpret_cast<uint16_t *>(sp + SL.perm);
-    SortedHeader *shdr = reinterpret_cast<SortedHeader *>(sp + SL.hdr);
-    int bshift = 0;                                        // element sums 0 .. 255 * d into SORT_BUCKETS buckets
-    while (((255u * (uint32_t)d) >> bshift) >= (uint32_t)SORT_BUCKETS) ++bshift;
-    const int grid = (int)((N + SORT_WIN - 1) / SORT_WIN);
+    if (!blocks) return fail(VQ_E_INVALID, "null pointer");
     const uintptr_t bp = reinterpret_cast<uintptr_t>(blocks);
-    DeviceInfo di;
-    int rc = device_info(di);
-    if (rc) return rc;
-    const size_t lds_need = (size_t)SORT_WIN * d + (size_t)SORT_WIN * 2 + (SORT_BUCKETS + 16) * 4 + 256;
-    // rows of 1 .. 4 aligned words: the window is staged in LDS and leaves in order (coalesced stores)
-    const bool words = (d % 4 == 0) && d <= 16 && (bp & 3) == 0 && (d != 16 || (bp & 15) == 0) &&
-                       (d != 8 || (bp & 7) == 0) && lds_need <= di.lds_per_block;
-    if (words) {
-        // rows staged in LDS, coalesced global traffic
-        const size_t lds = (size_t)SORT_WIN * d + (size_t)SORT_WIN * 2;
-        const uint32_t *b32 = reinterpret_cast<const uint32_t *>(blocks);
-        uint32_t *r32 = reinterpret_cast<uint32_t *>(rows);
-#define VQ_LAUNCH_SORT(DW)                                                                                          \
-    do {                                                                                                            \
-        auto kern = k_window_sort_lds<DW>;                                                                          \
-        if (lds > 48 * 1024)                                                                                        \
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                       \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, st, b32, N, bshift, r32, perm, shdr);                       \
-    } while (0)
-        switch (d / 4) {
-            case 1: VQ_LAUNCH_SORT(1); break;
-            case 2: VQ_LAUNCH_SORT(2); break;
-            case 3: VQ_LAUNCH_SORT(3); break;
-            default: VQ_LAUNCH_SORT(4); break;
-        }
-#undef VQ_LAUNCH_SORT
-    } else {
-        hipLaunchKernelGGL(k_window_sort, dim3(grid), dim3(1024), 0, st, blocks, N, d, bshift, rows, perm, shdr);
-    }
-    LAUNCH_CHECK("k_window_sort");
-    sorted_register(sorted, N, d, sorted_bytes);
-    return VQ_OK;
+    const bool words = (d % 4 == 0) && (bp & 3) == 0 && (d != 16 || (bp & 15) == 0) && (d != 8 || (bp & 7) == 0);
+    return run_sort(SrcBlocks{blocks, d}, words, N, d, sorted, sorted_bytes, static_cast<hipStream_t>(stream));
 }
 
-int vq_encode_l1_prepared(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d,
-                          const double *cb, int K, int32_t *labels, double *min_dist, void *ws, size_t ws_bytes,
-                          void *stream) {
-    int rc = check_common(blocks, N, d, cb, K);
+int vq_blocks_sort_img(const uint8_t *img, int H, int W, int C, int bh, int bw, int pad_mode, void *sorted,
+                       size_t sorted_bytes, void *stream) {
+    if (!img) return fail(VQ_E_INVALID, "null image pointer");
+    if (H <= 0 || W <= 0 || C <= 0 || bh <= 0 || bw <= 0) return fail(VQ_E_INVALID, "non-positive image or block size");
+    if (pad_mode != VQ_PAD_EDGE && pad_mode != VQ_PAD_ZERO) return fail(VQ_E_INVALID, "unknown pad_mode %d", pad_mode);
+    const int64_t nr = (H + bh - 1) / bh, nc = (W + bw - 1) / bw;
+    const int64_t d64 = (int64_t)bh * bw * C;
+    if (d64 > MAX_D_FAST) return fail(VQ_E_UNSUPPORTED, "d=%lld is beyond the fast kernels", (long long)d64);
+    const int d = (int)d64;
+    SrcImage src;
+    src.img = img; src.H = H; src.W = W; src.C = C; src.bh = bh; src.bw = bw; src.pad_zero = pad_mode == VQ_PAD_ZERO;
+    src.nc = (uint32_t)nc; src.seg = (uint32_t)(bw * C); src.d = (uint32_t)d;
+    src.words_ok = (((int64_t)W * C) % 4 == 0) && ((reinterpret_cast<uintptr_t>(img) & 3) == 0);
+    return run_sort(src, d % 4 == 0, nr * nc, d, sorted, sorted_bytes, static_cast<hipStream_t>(stream));
+}
+
+int vq_encode_l1_img(const uint8_t *img, int H, int W, int C, int bh, int bw, int pad_mode, const double *cb, int K,
+                     int32_t *labels, double *min_dist, void *scratch, size_t scratch_bytes, void *ws, size_t ws_bytes,
+                     void *stream) {
+    if (!img || !cb) return fail(VQ_E_INVALID, "null image or codebook pointer");
+    if (H <= 0 || W <= 0 || C <= 0 || bh <= 0 || bw <= 0) return fail(VQ_E_INVALID, "non-positive image or block size");
+    if (K <= 0) return fail(VQ_E_INVALID, "need K > 0");
+    if (K > MAX_K) return fail(VQ_E_UNSUPPORTED, "K=%d exceeds %d", K, MAX_K);
+    if (pad_mode != VQ_PAD_EDGE && pad_mode != VQ_PAD_ZERO) return fail(VQ_E_INVALID, "unknown pad_mode %d", pad_mode);
+    if (!labels || !scratch) return fail(VQ_E_INVALID, "null labels or scratch pointer");
+    const int64_t N = (int64_t)((H + bh - 1) / bh) * ((W + bw - 1) / bw);
+    const int64_t d64 = (int64_t)bh * bw * C;
+    if (d64 > (1 << 24)) return fail(VQ_E_UNSUPPORTED, "block too large");
+    const int d = (int)d64;
+    if (prune_supported(K, d)) {
+        // image -> window-sorted rows in one pass, then the pruned search on them: the block matrix is never built
+        int rc = check_ws(ws, ws_bytes, K, d, N);
+        if (rc) return rc;
+        rc = vq_blocks_sort_img(img, H, W, C, bh, bw, pad_mode, scratch, scratch_bytes, stream);
+        if (rc) return rc;
+        rc = run_prepare(cb, K, d, ws, static_cast<hipStream_t>(stream));
+        if (rc) return rc;
+        return run_fast(nullptr, scratch, scratch_bytes, N, d, cb, K, labels, min_dist, nullptr, nullptr, ws,
+                        static_cast<hipStream_t>(stream));
+    }
+    // shapes the pruned search does not serve: the scratch takes the plain block matrix
+    if (scratch_bytes < (size_t)N * d) return fail(VQ_E_WORKSPACE, "scratch of %zu bytes needed, %zu given", (size_t)N * d, scratch_bytes);
+    int rc = vq_blocks_u8(img, H, W, C, bh, bw, pad_mode, static_cast<uint8_t *>(scratch), stream);
+    if (rc) return rc;
+    return vq_encode_l1(static_cast<const uint8_t *>(scratch), N, d, cb, K, labels, min_dist, VQ_MODE_FAST, ws, ws_bytes, stream);
+}
+
+int vq_encode_l1_prepared_phases(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d,
+                                 const double *cb, int K, int32_t *labels, double *min_dist, int phases, void *ws,
+                                 size_t ws_bytes, void *stream) {
+    int rc = check_common(blocks, N, d, cb, K, sorted != nullptr && K > 0 && d > 0 && prune_supported(K, d));
     if (rc) return rc;
     if (!fast_supported(d)) return fail(VQ_E_UNSUPPORTED, "d=%d is beyond the prepared (fast) kernels", d);
     if (N > 0xfffffff0LL) return fail(VQ_E_UNSUPPORTED, "N=%lld exceeds 2^32 per call", (long long)N);
+    if (phases < 1 || phases > 3) return fail(VQ_E_INVALID, "phases must be 1 (filter), 2 (fix-up) or 3 (both)");
     rc = check_ws(ws, ws_bytes, K, d, N);
     if (rc) return rc;
     if (N == 0) return VQ_OK;
     if (!labels) return fail(VQ_E_INVALID, "null labels pointer");
     return run_fast(blocks, sorted, sorted_bytes, N, d, cb, K, labels, min_dist, nullptr, nullptr, ws,
-                    static_cast<hipStream_t>(stream));
+                    static_cast<hipStream_t>(stream), phases);
+}
+
+int vq_encode_l1_prepared(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d,
+                          const double *cb, int K, int32_t *labels, double *min_dist, void *ws, size_t ws_bytes,
+                          void *stream) {
+    return vq_encode_l1_prepared_phases(blocks, sorted, sorted_bytes, N, d, cb, K, labels, min_dist, 3, ws, ws_bytes, stream);
+}
+
+size_t vq_workspace_counters_offset(int K, int d, int64_t N) {
+    if (K <= 0 || d <= 0 || N < 0) return 0;
+    return ws_layout(K, d, N).qcount;
 }
 
 int vq_accum_labels(const uint8_t *blocks, int64_t N, int d, const int32_t *labels, int K, uint64_t *sums,
@@ -2479,7 +2692,7 @@ int vq_accum_labels(const uint8_t *blocks, int64_t N, int d, const int32_t *labe
     if (N < 0 || d <= 0 || K <= 0) return fail(VQ_E_INVALID, "need N >= 0, d > 0, K > 0");
     if (N == 0) return VQ_OK;
     if (!blocks || !labels || !sums || !counts) return fail(VQ_E_INVALID, "null pointer");
-    return run_accum(blocks, N, d, labels, nullptr, K, reinterpret_cast<unsigned long long *>(sums),
+    return run_accum(blocks, nullptr, N, d, labels, nullptr, K, reinterpret_cast<unsigned long long *>(sums),
                      reinterpret_cast<unsigned long long *>(counts), nullptr, static_cast<hipStream_t>(stream));
 }
 
@@ -2492,7 +2705,8 @@ int vq_numpy_sum_f64(const double *v, int64_t N, double *out, double *chunk_sums
 int vq_lbg_accum(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d, const double *cb,
                  int K, uint64_t *sums, uint64_t *counts, int32_t *labels, double *min_dist, double *dist_sum,
                  double *chunk_sums, int mode, void *ws, size_t ws_bytes, void *stream) {
-    int rc = check_common(blocks, N, d, cb, K);
+    const bool via_sorted = sorted != nullptr && mode == VQ_MODE_FAST && K > 0 && d > 0 && prune_supported(K, d);
+    int rc = check_common(blocks, N, d, cb, K, via_sorted);
     if (rc) return rc;
     if (!sums || !counts || !dist_sum) return fail(VQ_E_INVALID, "null sums, counts or dist_sum pointer");
     if (N != 0 && (!labels || !min_dist)) return fail(VQ_E_INVALID, "null labels or min_dist pointer");
@@ -2519,14 +2733,22 @@ int vq_lbg_accum(const uint8_t *blocks, const void *sorted, size_t sorted_bytes,
                 rc = run_fast(blocks, sorted, sorted_bytes, N, d, cb, K, labels, dist_in_accum ? nullptr : min_dist,
                               nullptr, nullptr, ws, st);
                 if (rc) return rc;
-                rc = run_accum(blocks, N, d, labels, cb, K, s64, c64, dist_in_accum ? min_dist : nullptr, st);
+                // the accumulation pass takes the rows from the sorted copy when the search did
+                const uint8_t *acc_rows = blocks;
+                const uint16_t *acc_perm = nullptr;
+                if (via_sorted) {
+                    SortedLayout SL = sorted_layout(d, N);
+                    acc_rows = reinterpret_cast<const uint8_t *>(static_cast<const char *>(sorted) + SL.rows);
+                    acc_perm = reinterpret_cast<const uint16_t *>(static_cast<const char *>(sorted) + SL.perm);
+                }
+                rc = run_accum(acc_rows, acc_perm, N, d, labels, cb, K, s64, c64, dist_in_accum ? min_dist : nullptr, st);
                 if (rc) return rc;
             }
         } else {
             int grid = grid_for(N, 256, 16384);
             hipLaunchKernelGGL(k_assign_exact, dim3(grid), dim3(256), 0, st, blocks, N, d, cb, K, labels, min_dist);
             LAUNCH_CHECK("k_assign_exact");
-            rc = run_accum(blocks, N, d, labels, cb, K, s64, c64, nullptr, st);
+            rc = run_accum(blocks, nullptr, N, d, labels, cb, K, s64, c64, nullptr, st);
             if (rc) return rc;
         }
     }

@@ -99,12 +99,60 @@ class HipEngine:
             check(lib.vq_blocks_sort(_ptr(blocks), N, d, _ptr(out), out.numel(), self._stream()), "vq_blocks_sort")
         return out
 
+    def sort_image(self, img, bh, bw, pad_mode=VQ_PAD_EDGE, out=None):
+        """Image -> window-sorted block vectors in one pass (padding, block extraction and the sort of
+        sort_blocks fused; VQ_Full.py:23-33, 51-57): the same buffer sort_blocks(blocks_from_image(img))
+        fills, without building the block matrix.  Returns (buffer, (N, d)), or (None, (N, d)) for
+        dimensions the fast kernels do not serve."""
+        img = self._dev(img, torch.uint8)
+        if img.dim() == 2:
+            img = img.unsqueeze(-1)
+        H, W, C = img.shape
+        if bh <= 0 or bw <= 0:
+            raise ValueError("Block height and width must be positive integers.")
+        N, d = (-(-H // bh)) * (-(-W // bw)), bh * bw * C
+        if d > 192 or N == 0:
+            return None, (N, d)
+        need = lib.vq_sorted_bytes(int(d), int(N))
+        if out is None or out.numel() < need:
+            out = torch.empty(need, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib.vq_blocks_sort_img(_ptr(img), H, W, C, bh, bw, pad_mode, _ptr(out), out.numel(), self._stream()),
+                  "vq_blocks_sort_img")
+        return out, (N, d)
+
+    def encode_image(self, img, bh, bw, cb, pad_mode=VQ_PAD_EDGE, want_dist=False, scratch=None, labels=None):
+        """Labels of an image's block vectors straight from the image (VQ_Full.py:23-57 + :124-125)."""
+        img = self._dev(img, torch.uint8)
+        if img.dim() == 2:
+            img = img.unsqueeze(-1)
+        H, W, C = img.shape
+        cb = self._dev(cb, torch.float64)
+        K, d = cb.shape
+        if d != bh * bw * C:
+            raise ValueError(f"codebook rows have {d} entries, blocks have {bh * bw * C}")
+        N = (-(-H // bh)) * (-(-W // bw))
+        need = max(int(lib.vq_sorted_bytes(int(d), int(N))), N * d, 16)
+        if scratch is None or scratch.numel() < need:
+            scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if labels is None:
+            labels = torch.empty(N, dtype=torch.int32, device=self.device)
+        mind = torch.empty(N, dtype=torch.float64, device=self.device) if want_dist else None
+        ws = self._workspace(K, d, N)
+        with torch.cuda.device(self.device):
+            check(lib.vq_encode_l1_img(_ptr(img), H, W, C, bh, bw, pad_mode, _ptr(cb), K, _ptr(labels), _ptr(mind),
+                                       _ptr(scratch), scratch.numel(), _ptr(ws), ws.numel(), self._stream()),
+                  "vq_encode_l1_img")
+        return (labels, mind) if want_dist else labels
+
     @staticmethod
     def prune_supported(K, d):
         return bool(lib.vq_prune_supported(int(K), int(d)))
 
-    def encode(self, blocks, cb, want_dist=False, mode=None, sorted=None):
-        N, d = blocks.shape
+    def encode(self, blocks, cb, want_dist=False, mode=None, sorted=None, shape=None):
+        """blocks may be None when `sorted` serves the codebook's shape (prune_supported); `shape` = (N, d)
+        then says what the sorted copy holds."""
+        N, d = blocks.shape if blocks is not None else shape
         cb = self._dev(cb, torch.float64)
         K = cb.shape[0]
         labels = torch.empty(N, dtype=torch.int32, device=self.device)
@@ -118,6 +166,8 @@ class HipEngine:
                 check(lib.vq_encode_l1_prepared(_ptr(blocks), _ptr(sorted), _nbytes(sorted), N, d, _ptr(cb), K, _ptr(labels), _ptr(mind),
                                                 _ptr(ws), ws.numel(), self._stream()), "vq_encode_l1_prepared")
             return (labels, mind) if want_dist else labels
+        if blocks is None:
+            raise ValueError("the block matrix is needed: the sorted copy does not serve this codebook shape or mode")
         with torch.cuda.device(self.device):
             check(lib.vq_encode_l1(_ptr(blocks), N, d, _ptr(cb), K, _ptr(labels), _ptr(mind),
                                    self.mode if mode is None else mode, _ptr(ws), ws.numel(), self._stream()),
@@ -136,24 +186,37 @@ class HipEngine:
                   "vq_codebook_prepare")
         return (cb, ws)
 
-    def encode_prepared(self, blocks, prepared, labels=None, want_dist=False, sorted=None):
+    def encode_prepared(self, blocks, prepared, labels=None, want_dist=False, sorted=None, shape=None, phases=3):
+        """phases: 1 = filter launch only, 2 = fix-up launch only (of the last filter pass), 3 = both."""
         cb, ws = prepared
-        N, d = blocks.shape
+        N, d = blocks.shape if blocks is not None else shape
         K = cb.shape[0]
         if labels is None:
             labels = torch.empty(N, dtype=torch.int32, device=self.device)
         mind = torch.empty(N, dtype=torch.float64, device=self.device) if want_dist else None
         with torch.cuda.device(self.device):
-            check(lib.vq_encode_l1_prepared(_ptr(blocks), _ptr(sorted), _nbytes(sorted), N, d, _ptr(cb), K, _ptr(labels), _ptr(mind),
-                                            _ptr(ws), ws.numel(), self._stream()), "vq_encode_l1_prepared")
+            check(lib.vq_encode_l1_prepared_phases(_ptr(blocks), _ptr(sorted), _nbytes(sorted), N, d, _ptr(cb), K,
+                                                   _ptr(labels), _ptr(mind), int(phases), _ptr(ws), ws.numel(),
+                                                   self._stream()), "vq_encode_l1_prepared_phases")
         return (labels, mind) if want_dist else labels
 
+    def search_statistics(self, prepared, N):
+        """(vectors queued for the fp64 fix-up, (vector, codeword) pairs evaluated) of the last filter pass
+        that used this prepared workspace on N vectors."""
+        cb, ws = prepared
+        K, d = cb.shape
+        off = lib.vq_workspace_counters_offset(int(K), int(d), int(N))
+        slots = ws[off: off + 64 * 64].clone()
+        queued = slots.view(torch.int32).reshape(64, 16)[:, 0].to(torch.int64).sum()
+        pairs = slots.view(torch.int64).reshape(64, 8)[:, 1].sum()
+        return int(queued.item()), int(pairs.item())
+
     # -- fused LBG assignment + accumulation (VQ_Full.py:77-90) -------------------------------------
-    def lbg_accum(self, blocks, cb, want_labels=False, mode=None, want_chunks=False, sorted=None):
+    def lbg_accum(self, blocks, cb, want_labels=False, mode=None, want_chunks=False, sorted=None, shape=None):
         """Returns (acc, dist_sum[, labels][, chunk_sums]); acc is one int64 buffer
         [K*d sums | K counts] so that a multi-GPU job can all-reduce it in one collective.  dist_sum
         is the sum of the winning distances in numpy's summation order."""
-        N, d = blocks.shape
+        N, d = blocks.shape if blocks is not None else shape
         cb = self._dev(cb, torch.float64)
         K = cb.shape[0]
         acc = torch.zeros(K * d + K, dtype=torch.int64, device=self.device)

@@ -2,9 +2,9 @@
 
 The engine does the per-vector work on its GPU; this module owns the split schedule, the
 stop rule and -- when the block vectors are sharded over several GPUs -- the per-iteration
-exchange: ONE all-gather of every rank's integer [sums | counts] buffer together with its fp64
-per-chunk distance sums; every rank then adds the integers and adds the distance partials in rank
-order.  Integer sums make the n-GPU
+exchange: one all-gather of every rank's integer [sums | counts] buffer together with its fp64
+per-chunk distance sums (large codebooks: an integer all-reduce plus a gather of the distance sums);
+every rank then adds the distance partials in rank order.  Integer sums make the n-GPU
 codebook identical to the 1-GPU one; with 8192-aligned shards the distortion (numpy's summation
 order) is identical too, so the stop rule fires at the same iteration.
 """
@@ -47,44 +47,68 @@ def _allreduce_sum_(t, group):
 NP_CHUNK = 8192   # elements per pairwise-summed chunk of numpy's reduction (and of vq_numpy_sum_f64)
 
 
-def shards_chunk_aligned(n_local, group):
+# Above this many bytes of [sums | counts] per rank, times the number of ranks, the integer part travels by
+# all-reduce (each rank moves about twice its own payload, whatever the rank count) and only the few fp64
+# chunk sums are gathered; below it one all-gather of everything is a single latency-bound message.
+ALLREDUCE_FROM_BYTES = 1 << 20
+
+
+def _all_gather_into(src, world, group):
+    """all_gather of equally sized 1-D tensors; returns a (world, n) tensor on src's device."""
+    import torch.distributed as dist
+    if dist.get_backend(group) == "gloo":                   # gloo moves host memory, one tensor per rank
+        h = src.cpu()
+        parts = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(parts, h, group=group)
+        return torch.stack(parts).to(src.device)
+    out = torch.empty((world, src.numel()), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(out.view(-1), src.contiguous(), group=group)
+    return out
+
+
+def shards_chunk_aligned(n_local, group, device=None):
     """True when the ranks' shards, concatenated in rank order, keep numpy's 8192-element chunk
-    boundaries inside shards: every rank but the last one holding data has a multiple of 8192."""
+    boundaries inside shards: every rank but the last one holding data has a multiple of 8192.
+    Returns (aligned, sizes); one small tensor all-gather."""
     import torch.distributed as dist
     world = dist.get_world_size(group=group)
-    sizes = [None] * world
-    dist.all_gather_object(sizes, int(n_local), group=group)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"
+    mine = torch.tensor([int(n_local)], dtype=torch.int64, device=device)
+    sizes = [int(v) for v in _all_gather_into(mine, world, group).reshape(-1).tolist()]
     holders = [r for r in range(world) if sizes[r] > 0]
     return all(sizes[r] % NP_CHUNK == 0 for r in holders[:-1]), sizes
 
 
 def _exchange(acc, dist_sum, chunks, sizes, aligned, group):
-    """The one collective of an LBG iteration.  Every rank contributes [sums | counts | its distance
-    partials] in one int64 buffer (the fp64 partials bit-cast); an all-gather hands every rank all of
-    them.  Returns (integer [sums | counts] added over the ranks, on acc's device; the global sum of
-    winning distances as a Python float).
+    """The exchange of an LBG iteration.  Every rank contributes its integer [sums | counts] and its fp64
+    distance partials.  Small payloads go out as ONE all-gather of one int64 buffer (the fp64 partials
+    bit-cast); large ones (K * (d + 1) * 8 * world beyond ALLREDUCE_FROM_BYTES) as an integer all-reduce plus
+    an all-gather of the distance partials alone.  Returns (integer [sums | counts] added over the ranks, on
+    acc's device; the global sum of winning distances as a Python float).
 
     With chunk-aligned shards the distance total is the left-to-right sum of every rank's per-chunk
     sums in rank order -- bit for bit what one process computes on the concatenated data; otherwise
-    the per-rank sums added in rank order."""
+    the per-rank sums added in rank order.  Integer sums do not depend on the order of addition, so both
+    routes give identical codebooks."""
     import numpy as np
     import torch.distributed as dist
     world = dist.get_world_size(group=group)
     nacc = acc.numel()
     width = max(1, max(-(-n // NP_CHUNK) for n in sizes)) if aligned else 1
-    payload = torch.zeros(nacc + width, dtype=torch.int64, device=acc.device)
-    payload[:nacc] = acc
-    tail = payload[nacc:].view(torch.float64)
+    tail = torch.zeros(width, dtype=torch.float64, device=acc.device)
     if aligned:
         tail[: chunks.numel()] = chunks
     else:
         tail[0] = dist_sum.reshape(-1)[0]
-    src = payload.cpu() if _needs_host_staging(payload, group) else payload
-    parts = [torch.empty_like(src) for _ in range(world)]
-    dist.all_gather(parts, src, group=group)
-    gathered = torch.stack(parts)                                   # (world, nacc + width)
-    acc_total = gathered[:, :nacc].sum(dim=0).to(acc.device)        # integers: any order gives the same sums
-    host = gathered[:, nacc:].contiguous().view(torch.float64).cpu().numpy()
+    if nacc * 8 * world > ALLREDUCE_FROM_BYTES:
+        acc_total = _allreduce_sum_(acc.clone(), group)
+        host = _all_gather_into(tail, world, group).cpu().numpy()
+    else:
+        payload = torch.cat([acc, tail.view(torch.int64)])
+        gathered = _all_gather_into(payload, world, group)             # (world, nacc + width)
+        acc_total = gathered[:, :nacc].sum(dim=0)                      # integers: any order gives the same sums
+        host = gathered[:, nacc:].contiguous().view(torch.float64).cpu().numpy()
     if aligned:
         seq = np.concatenate([host[r, : -(-sizes[r] // NP_CHUNK)] for r in range(world)])
         total = float(np.cumsum(seq)[-1]) if seq.size else 0.0     # cumsum adds strictly left to right
@@ -120,7 +144,7 @@ def lbg_iteration(engine, blocks, cb, n_total, group=None, shard_info=None, sort
         total = float(dist.item())
     else:
         if shard_info is None:
-            shard_info = shards_chunk_aligned(blocks.shape[0], group)
+            shard_info = shards_chunk_aligned(blocks.shape[0], group, blocks.device)
         aligned, sizes = shard_info
         acc, dist, chunks = engine.lbg_accum(blocks, cb, want_chunks=True, sorted=sorted)
         acc, total = _exchange(acc, dist, chunks, sizes, aligned, group)
@@ -146,7 +170,7 @@ def train_lbg(engine, blocks, k, epsilon=0.01, threshold=0.001, max_iterations=1
     cb = centroid
     if sorted is None:
         sorted = engine.sort_blocks(blocks)       # the vectors do not change: one sort serves every iteration
-    shard_info = shards_chunk_aligned(blocks.shape[0], group) if group is not None else None
+    shard_info = shards_chunk_aligned(blocks.shape[0], group, blocks.device) if group is not None else None
     iters, conv, distortions = [], [], []
     stage = 0
     while cb.shape[0] < k:
