@@ -59,13 +59,13 @@ def test_sorted_layout_and_prune_shapes():
         rows = (n * d + 255) // 256 * 256
         assert lib.vq_sorted_bytes(d, n) == rows + (2 * n + 255) // 256 * 256 + 256      # rows, origins, header
     assert lib.vq_sorted_bytes(16, 0) == 0 and lib.vq_sorted_bytes(0, 10) == 0
-    # scalar-load kernels only: d <= 64, 32 <= K <= 2048, fixed-point codebook within 32 KB
+    # every dimension of the SAD filter kernels (d <= 192), 32 <= K <= 4096
     assert lib.vq_prune_supported(256, 16) == 1 and lib.vq_prune_supported(1024, 16) == 1
     assert lib.vq_prune_supported(32, 4) == 1 and lib.vq_prune_supported(2048, 4) == 1
     assert lib.vq_prune_supported(16, 16) == 0          # too few codewords to be worth the bookkeeping
-    assert lib.vq_prune_supported(2048, 16) == 0        # 64 KB of fixed-point rows: LDS-staged variant
-    assert lib.vq_prune_supported(256, 48) == 1 and lib.vq_prune_supported(4096, 4) == 0
-    assert lib.vq_prune_supported(512, 48) == 0 and lib.vq_prune_supported(128, 64) == 1 and lib.vq_prune_supported(64, 66) == 0
+    assert lib.vq_prune_supported(2048, 16) == 1 and lib.vq_prune_supported(4096, 192) == 1
+    assert lib.vq_prune_supported(256, 48) == 1 and lib.vq_prune_supported(4096, 4) == 1
+    assert lib.vq_prune_supported(4097, 16) == 0 and lib.vq_prune_supported(64, 193) == 0
     assert lib.vq_prune_supported(0, 16) == 0 and lib.vq_prune_supported(256, 0) == 0
     # the workspace holds one queue slot per vector (plus padding) whatever the shape
     for n in (1, 63, 64, 65, 4096, 4097, 1 << 22):

@@ -281,3 +281,24 @@ def test_emu_encode_image(eng, oracle, shape, bh, bw, K):
         assert np.array_equal(labels.numpy(), want["labels"])
         assert np.array_equal(a[: K * d].reshape(K, d), want["sums"]) and np.array_equal(a[K * d:], want["counts"])
         assert dist.item() == oracle.numpy_sum(want["min_dist"])
+
+
+@pytest.mark.parametrize("K,d,N", [(40, 192, 700), (600, 48, 900), (2100, 16, 1300), (4096, 4, 1500), (33, 96, 500), (130, 66, 520)])
+def test_emu_pruned_search_lds_tiled(eng, oracle, K, d, N):
+    """Shapes whose codewords stream through LDS tiles (long rows, codebooks beyond the scalar cache), pruned
+    at workgroup granularity: encode and one LBG pass on data with spread-out element sums and near-ties."""
+    rng = np.random.default_rng(K * 13 + d)
+    blocks, cb = _structured(rng, K, d, N)
+    cb[K // 2] = cb[K // 3]                              # duplicate codeword
+    blocks[: N // 10] = np.clip(np.rint(cb[rng.integers(0, K, N // 10)]), 0, 255).astype(np.uint8)   # near-ties
+    want = oracle.lbg_iter(blocks, cb)
+    b = T(blocks)
+    srt = eng.sort_blocks(b)
+    assert eng.prune_supported(K, d)
+    got_l, got_d = eng.encode(b, T(cb), want_dist=True, mode=1, sorted=srt)
+    assert np.array_equal(got_l.numpy(), want["labels"]) and np.array_equal(got_d.numpy(), want["min_dist"])
+    acc, dist, labels = eng.lbg_accum(None, T(cb), want_labels=True, mode=1, sorted=srt, shape=blocks.shape)
+    a = acc.numpy().astype(np.uint64)
+    assert np.array_equal(labels.numpy(), want["labels"])
+    assert np.array_equal(a[: K * d].reshape(K, d), want["sums"]) and np.array_equal(a[K * d:], want["counts"])
+    assert dist.item() == oracle.numpy_sum(want["min_dist"])

@@ -319,7 +319,8 @@ def _pruned_case(eng, oracle, blocks, cb, want_dist=True):
 
 @pytest.mark.parametrize("K,d,N", [(32, 16, 5000), (64, 4, 20000), (255, 16, 9000), (256, 16, 40000), (1000, 16, 8192),
                                    (1024, 16, 12000), (2048, 4, 9000), (100, 27, 7000), (128, 32, 10000), (40, 12, 3000),
-                                   (300, 8, 16385)])
+                                   (300, 8, 16385), (2048, 16, 9000), (4096, 16, 5000), (512, 48, 8000), (300, 192, 4000),
+                                   (4096, 192, 3000), (1000, 96, 2500), (70, 130, 9000)])
 def test_encode_pruned_structured(eng, oracle, K, d, N):
     """Vectors and codewords with a wide spread of element sums (where pruning really skips rows)."""
     assert eng.prune_supported(K, d)
@@ -357,7 +358,8 @@ def test_encode_pruned_golden(eng, oracle, train_case):
     assert np.array_equal(got.reshape(g["labels"].shape), g["labels"])
 
 
-@pytest.mark.parametrize("K,d", [(256, 16), (64, 4), (1024, 16), (2048, 16), (128, 15), (64, 11), (32, 27), (256, 3)])
+@pytest.mark.parametrize("K,d", [(256, 16), (64, 4), (1024, 16), (2048, 16), (128, 15), (64, 11), (32, 27), (256, 3),
+                                 (256, 48), (600, 48), (512, 192), (4096, 8)])
 def test_lbg_iteration_pruned(eng, oracle, K, d):
     rng = np.random.default_rng(K * 3 + d)
     N = 20000

@@ -112,7 +112,7 @@ constexpr int MAX_K = 1 << 20;
 // below t << tshift; POSTAB_NT + 2 entries are used at most.
 constexpr int POSTAB_NT = 1024;
 constexpr int POSTAB_WORDS = POSTAB_NT + 8;
-constexpr int PREP_SORT_CAP = 2048;     // codebooks up to this size are sorted by element sum
+constexpr int PREP_SORT_CAP = 4096;     // codebooks up to this size are sorted by element sum
 constexpr int SORT_WIN = 8192;          // vectors per window of the windowed vector sort
 constexpr int SORT_BUCKETS = 2048;      // counting-sort buckets per window
 
@@ -437,7 +437,9 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
     __shared__ uint32_t s_cmax;
     __shared__ uint32_t s_emax;
     __shared__ uint32_t s_sc[PREP_SORT_CAP];        // element sum of each fixed-point row, original order
-    __shared__ uint32_t s_scs[PREP_SORT_CAP];       // the same sums in ascending order
+    // the same sums in ascending order: written after the duplicate scan is over, into the space of its hash
+    // table (K <= PREP_SORT_CAP codebooks get at least K * 4 bytes of dynamic LDS)
+    uint32_t *s_scs = reinterpret_cast<uint32_t *>(s_keys);
     const bool do_sort = K <= PREP_SORT_CAP;
     uint32_t *crow_out = do_sort ? c16u : c16;       // unsorted rows go to scratch first when sorting
     const bool scan_dups = K <= PREP_HASH_CAP && K > 1;
@@ -538,9 +540,10 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
     // phase C: row k is a duplicate when the first row with its hash is an earlier, bit-identical
     // row.  Identical rows give identical distances, so the later one can never win (ties go to the
     // lower index) and gets the never-competes bit.  A missed duplicate only costs re-checks.
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
-        uint32_t dup = 0;
-        if (scan_dups) {
+    uint32_t dupmask = 0;                                        // bit i: this thread's i-th row is a duplicate
+    if (scan_dups) {
+        int it = 0;
+        for (int k = threadIdx.x; k < K; k += blockDim.x, ++it) {
             const double *row = cb + (size_t)k * d;
             const unsigned long long h = s_rowhash[k];
             uint32_t slot = (uint32_t)(h % T);
@@ -559,22 +562,29 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
                 const unsigned long long *rj = reinterpret_cast<const unsigned long long *>(cb + (size_t)first * d);
                 int e = 0;
                 while (e < d && rj[e] == rowb[e]) ++e;
-                dup = e == d ? 1u : 0u;
+                if (e == d) dupmask |= 1u << it;
             }
         }
-        // phase D: position of the row in ascending (element sum, index) order, by counting
-        uint32_t pos = (uint32_t)k;
-        if (do_sort) {
-            const uint32_t me = s_sc[k];
-            pos = 0;
-            for (int j = 0; j < K; ++j) {
-                const uint32_t o = s_sc[j];
-                pos += (o < me || (o == me && j < k)) ? 1u : 0u;
+    }
+    __syncthreads();                                             // the hash table is free: s_scs may be written
+    // phase D: position of the row in ascending (element sum, index) order, by counting
+    {
+        int it = 0;
+        for (int k = threadIdx.x; k < K; k += blockDim.x, ++it) {
+            const uint32_t dup = scan_dups ? (dupmask >> it) & 1u : 0u;
+            uint32_t pos = (uint32_t)k;
+            if (do_sort) {
+                const uint32_t me = s_sc[k];
+                pos = 0;
+                for (int j = 0; j < K; ++j) {
+                    const uint32_t o = s_sc[j];
+                    pos += (o < me || (o == me && j < k)) ? 1u : 0u;
+                }
+                s_scs[pos] = me;
+                for (int p = 0; p < dp2; ++p) c16[(size_t)pos * dp2 + p] = c16u[(size_t)k * dp2 + p];
             }
-            s_scs[pos] = me;
-            for (int p = 0; p < dp2; ++p) c16[(size_t)pos * dp2 + p] = c16u[(size_t)k * dp2 + p];
+            bias[pos] = (uint32_t)k | (dup << 31);
         }
-        bias[pos] = (uint32_t)k | (dup << 31);
     }
     // pad rows: zeros with the never-competes bias, so that batches of codewords may run past K
     const int kpad = (K + 7) / 8 * 8;
@@ -924,7 +934,6 @@ constexpr int tile_k_for(int dp2) { return dp2 <= 8 ? 128 : (dp2 <= 16 ? 64 : (d
 template <int DP2, int R, int KEYMODE, bool LDS_CW, bool PRUNE, bool ACC = false>
 __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const AssignArgs a, const uint32_t *__restrict__ c16,
                                                      const uint32_t *__restrict__ bias) {
-    static_assert(!(PRUNE && LDS_CW), "pruning is built for the scalar-load variant");
     static_assert(!ACC || (PRUNE && DP2 <= 16), "the fused accumulation belongs to the pruned variant");
     // dynamic LDS, LDS_CW: [2 tiles of TILE_K * DP2 words][2 x TILE_K bias words]
     //              ACC:    [K * (d + 1) words of sums | count][per wave: 64 rows of EPL bytes, 64 labels]
@@ -1155,28 +1164,32 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
                 const int kk = t * TILE_K + tid;
                 preb = (tid < TILE_K && kk < K) ? bias[kk] : 0x80000000u;
             };
-            auto lstore = [&](int t) {
-                uint4 *dst = reinterpret_cast<uint4 *>(s_cw + (t & 1) * TILE_W);
+            auto lstore = [&](int slot) {
+                uint4 *dst = reinterpret_cast<uint4 *>(s_cw + slot * TILE_W);
 #pragma unroll
                 for (int l = 0; l < MAXL; ++l) {
                     const int i = tid + l * BLOCK;
                     if (i < NV) dst[i] = pre[l];
                 }
-                if (tid < TILE_K) s_b[(t & 1) * TILE_K + tid] = preb;
+                if (tid < TILE_K) s_b[slot * TILE_K + tid] = preb;
             };
             uint32_t vz = 0;
             asm volatile("" : "+v"(vz));
-            __syncthreads();                                   // the previous vector tile is done with the buffers
-            gload(0);
+            // tiles [tlo, thi) of the fixed-point codebook (workgroup-uniform range), double-buffered
+            auto run_tiles = [&](int tlo, int thi) {
+            if (tlo >= thi) return;
+            __syncthreads();                                   // whatever used the buffers before is done with them
+            gload(tlo);
             lstore(0);
             __syncthreads();
-            for (int t = 0; t < ntk; ++t) {
-                if (t + 1 < ntk) gload(t + 1);
+            for (int t = tlo; t < thi; ++t) {
+                const int slot = (t - tlo) & 1;
+                if (t + 1 < thi) gload(t + 1);
                 // vz is an opaque per-lane zero: it keeps the compiler from treating these (wave-uniform)
                 // LDS reads as scalar values, which it would move to scalar registers one
                 // v_readfirstlane at a time
-                const uint32_t *cwbuf = s_cw + (t & 1) * TILE_W + vz;
-                const uint32_t *bbuf = s_b + (t & 1) * TILE_K + vz;
+                const uint32_t *cwbuf = s_cw + slot * TILE_W + vz;
+                const uint32_t *bbuf = s_b + slot * TILE_K + vz;
                 if constexpr (DP2 <= 16) {
 #pragma unroll 2
                     for (int kk = 0; kk < TILE_K; ++kk) {
@@ -1216,10 +1229,80 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
                         finish(acc, bbuf[kk], t * TILE_K + kk);
                     }
                 }
-                if (t + 1 < ntk) lstore(t + 1);
+                if (t + 1 < thi) lstore(slot ^ 1);
                 __syncthreads();
             }
-            rows_searched = (uint32_t)(ntk * TILE_K);
+            };
+            if constexpr (!PRUNE) {
+                run_tiles(0, ntk);
+                rows_searched = (uint32_t)(ntk * TILE_K);
+            } else {
+                // The element-sum bound at workgroup granularity: the BLOCK * R vectors of the workgroup are
+                // neighbours in sorted order, every wave walks the same tiles, and the range of sorted rows
+                // still to search comes from the workgroup-wide worst "best SAD so far" (one LDS exchange and
+                // two barriers per round).  All range arithmetic is workgroup-uniform.
+                uint32_t *s_red = s_b + 2 * TILE_K;            // [0..15] per-wave values, [16..18] results
+                const int nwv = BLOCK >> 6, wv = tid >> 6;
+                auto wg_reduce = [&](uint32_t vmin, uint32_t vmax, uint32_t &omin, uint32_t &omax) {
+                    vmin = wave_reduce_u32<false>(vmin);
+                    vmax = wave_reduce_u32<true>(vmax);
+                    __syncthreads();
+                    if (lane == 0) {
+                        s_red[wv] = vmin;
+                        s_red[16 + wv] = vmax;
+                    }
+                    __syncthreads();
+                    uint32_t a0 = 0xffffffffu, a1 = 0u;
+                    for (int i = 0; i < nwv; ++i) {
+                        a0 = min(a0, s_red[i]);
+                        a1 = max(a1, s_red[16 + i]);
+                    }
+                    omin = __builtin_amdgcn_readfirstlane(a0);
+                    omax = __builtin_amdgcn_readfirstlane(a1);
+                };
+                uint32_t sxlo = 0xffffffffu, sxhi = 0u;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    uint32_t sx = 0;
+#pragma unroll
+                    for (int p = 0; p < DP2; ++p) sx = __builtin_amdgcn_sad_u16(x[r][p], 0u, sx);
+                    sxlo = min(sxlo, sx);
+                    sxhi = max(sxhi, sx);
+                }
+                wg_reduce(sxlo, sxhi, sxlo, sxhi);
+                const uint32_t tshift = a.hdr->tshift, nt = a.hdr->nt;
+                // tiles added per side and round: about 32 rows, at least one tile
+                constexpr int GT = TILE_K >= 32 ? 1 : 32 / TILE_K;
+                int ta = (int)(a.postab[((sxlo >> 1) + (sxhi >> 1)) >> tshift] / TILE_K) - GT / 2;
+                if (ta > ntk - GT) ta = ntk - GT;
+                if (ta < 0) ta = 0;
+                int tb = ta + GT < ntk ? ta + GT : ntk;
+                int l0 = ta, h0 = tb, l1 = 0, h1 = 0;          // tile segments still to search this round
+                for (;;) {
+                    run_tiles(l0, h0);
+                    run_tiles(l1, h1);
+                    uint32_t bm = 0, unused;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) bm = max(bm, m1[r]);
+                    wg_reduce(bm, bm, unused, bm);
+                    if (KEYMODE == KEY_PACKED) bm >>= kbits;   // worst "best SAD so far" of the workgroup
+                    uint32_t thr = bm + window;                // a codeword further away than this matters to no vector
+                    if (thr < bm) thr = 0xffffffffu;
+                    const uint32_t lo_sum = sxlo > thr ? sxlo - thr : 0u;
+                    const unsigned long long hi_sum = (unsigned long long)sxhi + thr;
+                    unsigned long long ih = (hi_sum >> tshift) + 1ull;
+                    if (ih > nt + 1ull) ih = nt + 1ull;
+                    const int tlo = (int)(a.postab[lo_sum >> tshift] / TILE_K);
+                    const int thi = (int)((a.postab[ih] + TILE_K - 1) / TILE_K);
+                    const int na = ta > tlo ? (ta - GT > tlo ? ta - GT : tlo) : ta;
+                    const int nb = tb < thi ? (tb + GT < thi ? tb + GT : thi) : tb;
+                    if (na == ta && nb == tb) break;
+                    l0 = na; h0 = ta; l1 = tb; h1 = nb;
+                    ta = na;
+                    tb = nb;
+                }
+                rows_searched = (uint32_t)((tb - ta) * TILE_K);
+            }
         }
         // statistics: (vector, codeword) pairs this wave evaluated, summed into the 64-bit word at byte 8 of
         // the wave's sub-queue slot
@@ -2004,7 +2087,7 @@ constexpr int r_prune_for(int dp2) { return dp2 <= 16 ? VQ_RP : 2; }
 template <int DP2, int KEYMODE, bool LDS_CW, bool PRUNE = false, bool ACC = false>
 int launch_assign_fast_t(const AssignArgs &a, const uint32_t *c16, const uint32_t *bias, int block, int grid,
                          size_t lds, hipStream_t st) {
-    constexpr int R = PRUNE ? r_prune_for(DP2) : (LDS_CW ? r_lds_for(DP2) : r_for(DP2));
+    constexpr int R = LDS_CW ? r_lds_for(DP2) : (PRUNE ? r_prune_for(DP2) : r_for(DP2));
     auto kern = k_assign_fast<DP2, R, KEYMODE, LDS_CW, PRUNE, ACC>;
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2022,25 +2105,23 @@ int launch_assign_fast_k(const AssignArgs &a, const uint32_t *c16, const uint32_
             if (packed) return launch_assign_fast_t<DP2, KEY_PACKED, false, true, true>(a, c16, bias, block, grid, lds, st);
             return launch_assign_fast_t<DP2, KEY_SPLIT, false, true, true>(a, c16, bias, block, grid, lds, st);
         }
-        if (!lds_cw && prune) {
-            if (packed) return launch_assign_fast_t<DP2, KEY_PACKED, false, true>(a, c16, bias, block, grid, lds, st);
-            return launch_assign_fast_t<DP2, KEY_SPLIT, false, true>(a, c16, bias, block, grid, lds, st);
-        }
-        if (!lds_cw) {
+        if (!lds_cw && !prune) {
             if (packed) return launch_assign_fast_t<DP2, KEY_PACKED, false>(a, c16, bias, block, grid, lds, st);
             return launch_assign_fast_t<DP2, KEY_SPLIT, false>(a, c16, bias, block, grid, lds, st);
         }
     }
-    if constexpr (DP2 > 16 && DP2 <= 32) {
-        // rows of 34 .. 64 bytes through scalar loads: the pruned search only (opt-in, see prune_supported)
+    if constexpr (DP2 <= 32) {
+        // scalar-load pruned search: rows up to 64 bytes (two vectors per lane beyond 32 bytes)
         if (!lds_cw && prune) {
             if (packed) return launch_assign_fast_t<DP2, KEY_PACKED, false, true>(a, c16, bias, block, grid, lds, st);
             return launch_assign_fast_t<DP2, KEY_SPLIT, false, true>(a, c16, bias, block, grid, lds, st);
         }
+        if (packed) {
+            if (prune) return launch_assign_fast_t<DP2, KEY_PACKED, true, true>(a, c16, bias, block, grid, lds, st);
+            return launch_assign_fast_t<DP2, KEY_PACKED, true>(a, c16, bias, block, grid, lds, st);
+        }
     }
-    if constexpr (DP2 <= 32) {
-        if (packed) return launch_assign_fast_t<DP2, KEY_PACKED, true>(a, c16, bias, block, grid, lds, st);
-    }
+    if (prune) return launch_assign_fast_t<DP2, KEY_SPLIT, true, true>(a, c16, bias, block, grid, lds, st);
     return launch_assign_fast_t<DP2, KEY_SPLIT, true>(a, c16, bias, block, grid, lds, st);
 }
 
@@ -2150,7 +2231,9 @@ int run_prepare(const double *cb, int K, int d, void *ws, hipStream_t st) {
     const int dp2 = dp2_bucket(d);
     WsLayout L = ws_layout(K, d, 0);
     char *w = static_cast<char *>(ws);
-    const size_t hash_lds = (K <= PREP_HASH_CAP && K > 1) ? (size_t)K * 32 : 16;   // 2K keys + K hashes + 2K indices
+    // 2K keys + K hashes + 2K indices; afterwards the first K * 4 bytes hold the sorted element sums
+    const size_t hash_lds = (K <= PREP_HASH_CAP && K > 1) ? (size_t)K * 32 : 16;
+    static_assert(PREP_SORT_CAP <= PREP_HASH_CAP, "sorted codebooks have a hash table to put their sums in");
     if (hash_lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_prepare), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)hash_lds));
@@ -2211,15 +2294,19 @@ int sorted_check(const void *sorted, size_t sorted_bytes, int64_t N, int d) {
     return VQ_OK;
 }
 
-// The pruned search serves the shapes of the scalar-load kernels, from the codebook size on at
-// which skipping codewords can pay for the bookkeeping.
+// Whether a pruned search takes its codewords through scalar loads: the shapes of the scalar-load kernels,
+// and rows of 34 .. 64 bytes (RGB 4x4 blocks are 48; two vectors per lane) while the fixed-point codebook
+// fits the scalar cache budget.  Everything else streams codeword tiles through LDS.
+bool prune_by_scalar_loads(int K, int dp2) {
+    if (!use_lds_codewords(K, dp2)) return true;
+    return VQ_PRUNE_WIDE != 0 && dp2 <= 32 && (size_t)K * dp2 * 4 <= 32 * 1024;
+}
+
+// The pruned search needs the codebook sorted by element sum (K <= PREP_SORT_CAP) and pays from the
+// codebook size on at which skipping codewords can cover the bookkeeping.
 bool prune_supported(int K, int d) {
     const int dp2 = dp2_bucket(d);
-    if (dp2 <= 0 || K < 32 || K > PREP_SORT_CAP) return false;
-    if (!use_lds_codewords(K, dp2)) return true;
-    // Rows of 34 .. 64 bytes (RGB 4x4 blocks are 48) whose fixed-point codebook still fits the scalar
-    // cache budget are served by the same kernel with two vectors per lane.
-    return VQ_PRUNE_WIDE != 0 && dp2 <= 32 && (size_t)K * dp2 * 4 <= 32 * 1024;
+    return dp2 > 0 && K >= 32 && K <= PREP_SORT_CAP;
 }
 
 // FAST mode on a prepared workspace: the filter kernel, then the fp64 fix-up of the vectors it
@@ -2232,7 +2319,8 @@ size_t fused_acc_lds(int K, int d) {
 
 // Whether run_fast can accumulate sums / counts itself (pruned kernel, table within a quarter of the LDS).
 bool fused_acc_supported(const void *sorted, int K, int d) {
-    return sorted != nullptr && prune_supported(K, d) && dp2_bucket(d) <= 16 && fused_acc_lds(K, d) <= 40 * 1024;
+    return sorted != nullptr && prune_supported(K, d) && dp2_bucket(d) <= 16 && !use_lds_codewords(K, dp2_bucket(d)) &&
+           fused_acc_lds(K, d) <= 40 * 1024;
 }
 
 // sums / counts non-null (only with fused_acc_supported): cluster sums are accumulated too.
@@ -2264,11 +2352,12 @@ int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int
     const int kbits = ceil_log2(K);
     const bool packed = key_layout(K, dp2).packed;
     const bool prune = sorted != nullptr && prune_supported(K, d);
-    const bool lds_cw = use_lds_codewords(K, dp2) && !prune;       // the pruned search always takes scalar loads
-    const int R = prune ? r_prune_for(dp2) : (lds_cw ? r_lds_for(dp2) : r_for(dp2));
+    const bool lds_cw = prune ? !prune_by_scalar_loads(K, dp2) : use_lds_codewords(K, dp2);
+    const int R = lds_cw ? r_lds_for(dp2) : (prune ? r_prune_for(dp2) : r_for(dp2));
     const int block = 256;
     if (sums && !fused_acc_supported(sorted, K, d)) return fail(VQ_E_HIP, "internal: fused accumulation is not available here");
-    const size_t lds = lds_cw ? (size_t)2 * tile_k_for(dp2) * (dp2 + 1) * 4 : (sums ? fused_acc_lds(K, d) : 0);
+    // LDS-staged codewords: two tiles of rows and biases, plus the words of the workgroup reductions
+    const size_t lds = lds_cw ? (size_t)2 * tile_k_for(dp2) * (dp2 + 1) * 4 + 128 : (sums ? fused_acc_lds(K, d) : 0);
     const int64_t tile = (int64_t)block * R;
     const int64_t ntiles = (N + tile - 1) / tile;
     // One tile per workgroup: the dispatcher balances the chip and the last, partly filled round of
