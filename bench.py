@@ -323,14 +323,22 @@ def main():
     n_total = world * N
     cur = cb
     shard_info = shards_chunk_aligned(N, group, device) if distributed else None
-    for _ in range(3):
-        cur, _ = lbg_iteration(eng, blocks, cur, n_total, group, shard_info, sorted=srt)
+    lbg_steps = max(5, args.steps // 2)
+
+    def lbg_run(cur, steps):
+        if distributed:
+            for _ in range(steps):
+                # the vectors do not change between iterations: the sort made above serves all of them
+                cur, _ = lbg_iteration(eng, blocks, cur, n_total, group, shard_info, sorted=srt)
+            return cur
+        # one GPU: what train_lbg runs -- a stage of `steps` iterations with the stop rule on the device
+        # (threshold < 0: it never holds), iteration j + 1 enqueued before the outcome of iteration j is read
+        return eng.lbg_stage(blocks, cur, n_total, -1.0, steps, sorted=srt)[0]
+
+    cur = lbg_run(cur, 3)
     barrier()
     t0 = time.perf_counter()
-    lbg_steps = max(5, args.steps // 2)
-    for _ in range(lbg_steps):
-        # the vectors do not change between iterations: the sort made above serves all of them
-        cur, _ = lbg_iteration(eng, blocks, cur, n_total, group, shard_info, sorted=srt)
+    cur = lbg_run(cur, lbg_steps)
     barrier()
     lbg_elapsed = time.perf_counter() - t0
     t = torch.tensor([lbg_elapsed], dtype=torch.float64, device=device)

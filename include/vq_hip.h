@@ -159,6 +159,23 @@ int vq_lbg_accum(const uint8_t *blocks, const void *sorted, size_t sorted_bytes,
                  const double *cb, int K, uint64_t *sums, uint64_t *counts, int32_t *labels, double *min_dist,
                  double *dist_sum, double *chunk_sums, int mode, void *ws, size_t ws_bytes, void *stream);
 
+/* A whole LBG iteration in one call, with the stop rule on the device.  Replaces one trip of the loop at
+ * VQ_Full.py:76-98 on one GPU: vq_lbg_accum (sums / counts are zeroed here first and serve as scratch), then
+ * the centroid update IN PLACE in cb (VQ_Full.py:81-88) and the rule of VQ_Full.py:89-98: the distortion
+ * D = (numpy-order distance sum) / n_total is stored in the stage's state, and the iteration is marked
+ * converged when |prev - D| / prev < threshold (never at a stage's first iteration).  The state lives in
+ * device memory (vq_lbg_state_bytes(max_iterations) bytes; vq_lbg_stage_begin resets it at the start of
+ * every split stage), so the host can enqueue iteration i + 1 before it has read the outcome of iteration
+ * i: once an iteration has met the rule, the kernels of later iterations of that stage return at once
+ * and leave cb and the records untouched.  Record i sits at byte 64 + 16 * i of the state:
+ * { double distortion; uint32 converged; uint32 valid } -- valid = 0 marks an iteration that was skipped.
+ * A negative threshold never converges (forced iteration counts). */
+size_t vq_lbg_state_bytes(int max_iterations);
+int vq_lbg_stage_begin(void *state, size_t state_bytes, int max_iterations, void *stream);
+int vq_lbg_iterate(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d, double *cb, int K,
+                   int64_t n_total, double threshold, int iteration, uint64_t *sums, uint64_t *counts, int32_t *labels,
+                   double *min_dist, int mode, void *state, size_t state_bytes, void *ws, size_t ws_bytes, void *stream);
+
 /* Sum of an fp64 vector in the order numpy.add.reduce uses on a contiguous array (what np.mean
  * does before dividing, VQ_Full.py:90): pairwise summation -- runs of up to 128 elements with
  * eight interleaved partial sums, halved recursively -- inside chunks of 8192 elements, the chunk

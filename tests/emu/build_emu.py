@@ -23,8 +23,6 @@ unsigned char g_lds[LDS_BYTES] __attribute__((aligned(256)));
 int g_cus = 4;
 }
 thread_local emu::Idx threadIdx, blockIdx, blockDim, gridDim;
-// the codebook size from which the fix-up pass prunes, as a variable the tests can lower
-extern "C" { int emu_fixup_prune_min_k = 512; }
 '''
 
 
@@ -65,7 +63,7 @@ def build(force=False):
     with open(cpp, "w") as f:
         f.write(transform(open(SRC).read()))
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-pthread", "-w",
-           "-DVQ_FIXUP_PRUNE_MIN_K=emu_fixup_prune_min_k",
+
            "-I", HERE, "-I", os.path.join(ROOT, "include"), cpp, "-o", OUT]
     subprocess.run(cmd, check=True)
     return OUT

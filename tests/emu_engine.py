@@ -88,6 +88,12 @@ class EmuEngine(engine_mod.HipEngine):
     def _stream(self):
         return ctypes.c_void_p(0)
 
+    def _mark(self):
+        return None
+
+    def _read_bytes(self, buf, off, nbytes, mark):
+        return buf[off: off + nbytes].numpy().copy()
+
     def synchronize(self):
         pass
 

@@ -213,9 +213,8 @@ def test_emu_pruned_search_for_wide_rows(eng, oracle, K, d, N):
 
 @pytest.mark.parametrize("K,d,N,use_sorted", [(64, 16, 800, True), (200, 12, 500, False), (33, 48, 300, False), (2, 16, 300, False)])
 def test_emu_pruned_fixup(eng, oracle, K, d, N, use_sorted):
-    """The fix-up pass with the element-sum bound (the library uses it from K = 512 on; the emulated build
-    exposes that threshold as a variable so that small cases reach the kernel) on data full of exact ties
-    and near-ties, so that most vectors are queued: labels, distances and cluster sums as the oracle's."""
+    """The fix-up pass with the element-sum bound on data full of exact ties and near-ties, so that most
+    vectors are queued: labels, distances and cluster sums as the oracle's."""
     rng = np.random.default_rng(K * 11 + d)
     base = np.clip(rng.random((max(2, K // 3), 1)) * 255 + rng.normal(0, 15, (max(2, K // 3), d)), 0, 255)
     cb = base[rng.integers(0, len(base), K)] + rng.choice([0.0, 0.001, -0.002, 0.5], size=(K, 1))     # twins and near-twins
@@ -223,15 +222,8 @@ def test_emu_pruned_fixup(eng, oracle, K, d, N, use_sorted):
     want = oracle.lbg_iter(blocks, cb)
     b = T(blocks)
     srt = eng.sort_blocks(b) if use_sorted else None
-    import ctypes
-    from emu_engine import emu_lib
-    min_k = ctypes.c_int.in_dll(emu_lib(), "emu_fixup_prune_min_k")
-    saved, min_k.value = min_k.value, 0
-    try:
-        got_l, got_d = eng.encode(b, T(cb), want_dist=True, mode=1, sorted=srt)
-        acc, dist, labels = eng.lbg_accum(b, T(cb), want_labels=True, mode=1, sorted=srt)
-    finally:
-        min_k.value = saved
+    got_l, got_d = eng.encode(b, T(cb), want_dist=True, mode=1, sorted=srt)
+    acc, dist, labels = eng.lbg_accum(b, T(cb), want_labels=True, mode=1, sorted=srt)
     assert np.array_equal(got_l.numpy(), want["labels"]) and np.array_equal(got_d.numpy(), want["min_dist"])
     a = acc.numpy().astype(np.uint64)
     assert np.array_equal(labels.numpy(), want["labels"])

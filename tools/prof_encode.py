@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Profiling target: the kernels of the headline workload (8192 x 8192 gray, 4x4 blocks, K=256) only (no host baseline, few launches).
-Run under rocprofv3 --kernel-trace / --pmc.  Usage: python3 tools/prof_encode.py [reps]"""
+"""Profiling target: the kernels of the headline workload (8192 x 8192 gray, 4x4 blocks, K=256) only (no host
+baseline, few launches).  Run under rocprofv3 --kernel-trace / --pmc.  Usage: python3 tools/prof_encode.py [reps]"""
 import os
 import sys
 
@@ -8,30 +8,28 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import structured_image  # noqa: E402
-from vector_quantization_amd import HipEngine, train_lbg  # noqa: E402
+from vector_quantization_amd import HipEngine, train_lbg, lbg_iteration  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 dev = torch.device("cuda:0")
 eng = HipEngine(dev)
 img = structured_image(8192, 8192, 1000, dev)
 blocks = eng.blocks_from_image(img, 4, 4)
+N = blocks.shape[0]
 crop = eng.blocks_from_image(structured_image(2048, 2048, 0, dev), 4, 4)
 cb = train_lbg(eng, crop, 256, log=None).codebook
-prepared = eng.prepare_codebook(cb, blocks.shape[0])
-labels = torch.empty(blocks.shape[0], dtype=torch.int32, device=dev)
+prepared = eng.prepare_codebook(cb, N)
+labels = torch.empty(N, dtype=torch.int32, device=dev)
 torch.cuda.synchronize()
-srt = eng.sort_blocks(blocks)
+srt, _ = eng.sort_image(img, 4, 4)
 for _ in range(reps):
     eng.encode_prepared(blocks, prepared, labels=labels)                 # full search
 for _ in range(reps):
-    srt = eng.sort_blocks(blocks, out=srt)
-    eng.encode_prepared(blocks, prepared, labels=labels, sorted=srt)     # window sort + pruned search
-for _ in range(reps):
+    eng.encode_image(img, 4, 4, cb, scratch=srt, labels=labels)          # image sort + prepare + pruned search + fix-up
     eng.decode(labels.view(2048, 2048), cb, 4, 4, 1)
+cur = cb
 for _ in range(reps):
-    eng.lbg_accum(blocks, cb)
-for _ in range(reps):
-    eng.lbg_accum(blocks, cb, sorted=srt)
+    cur, _ = lbg_iteration(eng, blocks, cur, N, sorted=srt)              # fused LBG iteration
 for _ in range(reps):
     eng.blocks_from_image(img, 4, 4)
 torch.cuda.synchronize()

@@ -20,7 +20,7 @@ VQ_MODE_FAST = 1
 VQ_PAD_EDGE = 0
 VQ_PAD_ZERO = 1
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -48,6 +48,9 @@ SIGNATURES = {
     "vq_encode_l1_prepared_phases": (_i, [_vp, _vp, _sz, _i64, _i, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp]),
     "vq_workspace_counters_offset": (_sz, [_i, _i, _i64]),
     "vq_lbg_accum": (_i, [_vp, _vp, _sz, _i64, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "vq_lbg_state_bytes": (_sz, [_i]),
+    "vq_lbg_stage_begin": (_i, [_vp, _sz, _i, _vp]),
+    "vq_lbg_iterate": (_i, [_vp, _vp, _sz, _i64, _i, _vp, _i, _i64, _dbl, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _sz, _vp]),
     "vq_numpy_sum_f64": (_i, [_vp, _i64, _vp, _vp, _vp]),
     "vq_accum_labels": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp, _vp]),
     "vq_lbg_finalize": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),

@@ -36,6 +36,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <stdarg.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -76,7 +77,7 @@ int fail(int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(VQ_E_HIP, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
     } while (0)
 
-constexpr int ABI_VERSION = 4;
+constexpr int ABI_VERSION = 5;
 constexpr int WAVE = 64;
 constexpr int64_t NP_CHUNK = 8192;      // numpy's reduction buffer: elements per pairwise-summed chunk
 constexpr int MAX_D_FAST = 192;         // largest vector dimension of the SAD filter kernels
@@ -99,13 +100,12 @@ constexpr int MAX_K = 1 << 20;
 #ifndef VQ_GP
 #define VQ_GP 16
 #endif
+#ifndef VQ_G0
+#define VQ_G0 16
+#endif
 // Pruned search for rows of 34 .. 64 bytes (0 = such rows take the LDS-tiled full search).
 #ifndef VQ_PRUNE_WIDE
 #define VQ_PRUNE_WIDE 1
-#endif
-// Smallest codebook for which the fix-up pass uses the element-sum bound (k_fixup_pruned).
-#ifndef VQ_FIXUP_PRUNE_MIN_K
-#define VQ_FIXUP_PRUNE_MIN_K 512
 #endif
 
 // Sorted-codebook position table: entry t = number of codewords whose fixed-point element sum is
@@ -139,7 +139,7 @@ struct WsLayout {
     size_t c16u;       // K * dp2 uint32: the same rows in original order (scratch of the prepare kernel)
     size_t postab;     // POSTAB_WORDS uint32: sum threshold -> position in the sorted codebook
     size_t acc_rep;    // NREP * K * (d + 1) uint64: replicas of the [sums | count] table (fused accumulation)
-    size_t cbT;        // d * K doubles: transposed fp64 codebook
+    size_t cbT;        // d * K doubles: transposed fp64 codebook, columns in the order of the c16 rows
     size_t cb_u8;      // K * d bytes: codebook truncated to uint8 (decode)
     size_t chunks;     // ceil(N / 8192) + 1 doubles: per-chunk sums of the distance array
     size_t qcount;     // NQ counters, 64 bytes apart: entries in each sub-queue of ambiguous vectors
@@ -193,6 +193,36 @@ struct SortedHeader {
     uint32_t pad[60];
 };
 static_assert(sizeof(SortedHeader) == 256, "header is one 256-byte slot");
+
+// Gate of the kernels that vq_lbg_iterate enqueues.  The host enqueues iteration `iter` of a stage before it
+// knows whether an earlier iteration met the stop rule; the stage's device-resident state records the
+// iteration after which the stage stopped, and the kernels of later iterations return at once.
+struct Gate {
+    const int32_t *stopped_after;    // null: no gate (every other entry point)
+    int iter;
+};
+__device__ __forceinline__ bool gate_closed(const Gate &g) { return g.stopped_after != nullptr && *g.stopped_after < g.iter; }
+// the gate the launches of the calling thread carry (set for the duration of vq_lbg_iterate only)
+thread_local Gate g_gate = {nullptr, 0};
+// set by vq_lbg_iterate when it has already zeroed the queue counters and the replica tables of the workspace
+// together with the caller's sums / counts (one launch instead of four fills)
+thread_local bool g_ws_zeroed = false;
+
+// Device-resident state of one LBG stage (vq_lbg_stage_begin / vq_lbg_iterate).
+struct LbgRecord {
+    double distortion;               // mean winning distance of this iteration (VQ_Full.py:90)
+    uint32_t converged;              // 1: the stop rule of VQ_Full.py:92-94 held at this iteration
+    uint32_t valid;                  // 1: the iteration ran (0: it was gated off)
+};
+struct LbgState {
+    int32_t stopped_after;           // iteration at which the stop rule held (INT32_MAX while running)
+    uint32_t pad0;
+    double prev;                     // previous iteration's distortion (+inf before the first)
+    double dist_sum;                 // numpy-order sum of the winning distances of the current iteration
+    double pad1[5];
+    LbgRecord rec[1];                // one per iteration of the stage
+};
+static_assert(offsetof(LbgState, rec) == 64, "records start at byte 64");
 
 // ------------------------------------------------------------------------------------------------
 // device helpers
@@ -415,6 +445,63 @@ __global__ __launch_bounds__(256) void k_finalize(const unsigned long long *__re
     }
 }
 
+// Centroid update in place plus the stop rule (VQ_Full.py:81-98), for iteration g.iter of a stage: cb[k] =
+// sums[k] / counts[k] for non-empty clusters (empty ones keep their codeword); thread 0 of workgroup 0 turns
+// the distance sum into the distortion D = sum / n_total, records it, and applies the rule
+// |prev - D| / prev < threshold (never at the first iteration, where prev is +inf; a zero prev gives NaN
+// or +inf, which never satisfies it -- as in the reference).
+__global__ __launch_bounds__(256) void k_finalize_rule(const unsigned long long *__restrict__ sums,
+                                                       const unsigned long long *__restrict__ counts, double *cb, int K,
+                                                       int d, double n_total, double threshold, LbgState *state, Gate g) {
+    if (gate_closed(g)) return;
+    int64_t n = (int64_t)K * d;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        unsigned long long c = counts[i / d];
+        if (c) cb[i] = (double)sums[i] / (double)c;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const double D = state->dist_sum / n_total;
+        const double prev = state->prev;
+        uint32_t conv = 0;
+        if (prev != __builtin_huge_val()) {
+            const double change = fabs(prev - D) / prev;
+            conv = change < threshold ? 1u : 0u;
+        }
+        state->rec[g.iter].distortion = D;
+        state->rec[g.iter].converged = conv;
+        state->rec[g.iter].valid = 1u;
+        state->prev = D;
+        if (conv) state->stopped_after = g.iter;          // later iterations of this stage are gated off
+    }
+}
+
+// Zeroes up to four regions (16-byte aligned starts, sizes multiples of 16 bytes) in one launch.
+struct ZeroRegions {
+    uint4 *p[4];
+    size_t n16[4];                   // 16-byte pieces per region
+};
+__global__ __launch_bounds__(256) void k_zero_regions(const ZeroRegions z) {
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < z.n16[r]; i += stride) z.p[r][i] = zero;
+}
+
+__global__ void k_lbg_stage_begin(LbgState *state, int max_iterations) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        state->stopped_after = 0x7fffffff;
+        state->prev = __builtin_huge_val();
+        state->dist_sum = 0.0;
+    }
+    if (i < max_iterations) {
+        state->rec[i].distortion = 0.0;
+        state->rec[i].converged = 0u;
+        state->rec[i].valid = 0u;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // codebook preparation for the SAD filter (one workgroup)
 // ------------------------------------------------------------------------------------------------
@@ -509,7 +596,7 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
                             err += de;
                             pair |= ((uint32_t)q) << (16 * hh);
                             sc += (uint32_t)q;
-                            cbT[(size_t)e * K + k] = cv;
+                            if (!do_sort) cbT[(size_t)e * K + k] = cv;   // sorted codebooks: written in phase D
                             h = mix64(h, (unsigned long long)__double_as_longlong(cv));
                         }
                     }
@@ -582,6 +669,8 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
                 }
                 s_scs[pos] = me;
                 for (int p = 0; p < dp2; ++p) c16[(size_t)pos * dp2 + p] = c16u[(size_t)k * dp2 + p];
+                // the transposed fp64 copy follows the sorted order too: cbT[e][pos]
+                for (int e = 0; e < d; ++e) cbT[(size_t)e * K + pos] = cb[(size_t)k * d + e];
             }
             bias[pos] = (uint32_t)k | (dup << 31);
         }
@@ -900,6 +989,7 @@ struct AssignArgs {
     const uint16_t *perm;       // N: position inside its window of the vector now at sorted position i
     const uint32_t *postab;     // sum threshold -> position in the sorted codebook
     const SortedHeader *shdr;   // what the sorted copy holds (verified before the origin map is trusted)
+    Gate gate;
 };
 
 // Codewords per LDS tile of the LDS_CW variant (about 4 KB of fixed-point rows per tile).
@@ -936,16 +1026,20 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
                                                      const uint32_t *__restrict__ bias) {
     static_assert(!ACC || (PRUNE && DP2 <= 16), "the fused accumulation belongs to the pruned variant");
     // dynamic LDS, LDS_CW: [2 tiles of TILE_K * DP2 words][2 x TILE_K bias words]
-    //              ACC:    [K * (d + 1) words of sums | count][per wave: 64 rows of EPL bytes, 64 labels]
+    //              ACC:    [(K + 1) rows of 2*DP2 byte sums | count | pad][per wave: 64 rows of EPL bytes, 64 labels]
     extern __shared__ __align__(16) uint32_t s_tab[];
+    if (gate_closed(a.gate)) return;
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int BLOCK = blockDim.x;
     const int d = a.d, K = a.K;
     const bool want_dist = a.min_dist != nullptr;
     constexpr int EPL = 2 * DP2;                               // staged bytes per row (elements beyond d are zero)
-    const int tabn = K * (d + 1);                              // row K of the LDS table is a dummy (never flushed)
-    uint8_t *st_rows = reinterpret_cast<uint8_t *>(s_tab + ((tabn + d + 1 + 3) & ~3)) + (tid >> 6) * (WAVE * EPL + WAVE * 4);
+    // LDS table of the fused accumulation: K rows of TROW words -- EPL byte sums (those beyond d stay zero), the
+    // member count, one pad word, so that element pairs sit on 8-byte boundaries; row K is a dummy (never flushed)
+    constexpr int TROW = EPL + 2;
+    const int tabn = K * TROW;
+    uint8_t *st_rows = reinterpret_cast<uint8_t *>(s_tab + ((tabn + TROW + 3) & ~3)) + (tid >> 6) * (WAVE * EPL + WAVE * 4);
     int32_t *st_lbl = reinterpret_cast<int32_t *>(st_rows + WAVE * EPL);
     if (ACC) {
         for (int i = tid; i < tabn; i += BLOCK) s_tab[i] = 0u;
@@ -1105,10 +1199,11 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
                 sxhi = wave_reduce_u32<true>(sxhi);
                 const uint32_t tshift = a.hdr->tshift, nt = a.hdr->nt;
                 constexpr int G = VQ_GP;                       // codewords added per side and round
-                int pa = (int)(a.postab[((sxlo >> 1) + (sxhi >> 1)) >> tshift] & ~7u) - G / 2;
-                if (pa > kpad - G) pa = kpad - G;
+                constexpr int G0 = VQ_G0;                      // codewords of the first round, around the wave's own sum
+                int pa = (int)(a.postab[((sxlo >> 1) + (sxhi >> 1)) >> tshift] & ~7u) - G0 / 2;
+                if (pa > kpad - G0) pa = kpad - G0;
                 if (pa < 0) pa = 0;
-                int pb = pa + G < kpad ? pa + G : kpad;
+                int pb = pa + G0 < kpad ? pa + G0 : kpad;
                 // segments still to search this round: [l0, h0) and [l1, h1); [pa, pb) is what has been searched
                 int l0 = pa, h0 = pb, l1 = 0, h1 = 0;
                 for (;;) {
@@ -1355,33 +1450,28 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
                     const uint32_t w = __builtin_amdgcn_perm(x[r][p + 1] >> s, x[r][p] >> s, 0x06040200u);
                     *reinterpret_cast<uint32_t *>(st_rows + lane * EPL + 2 * p) = w;
                 }
-                st_lbl[lane] = (settled ? idx : K) * (d + 1) * 4;
+                st_lbl[lane] = (settled ? idx : K) * TROW * 4;
                 // the staging area belongs to this wave alone and a wave's LDS operations complete in order:
                 // only the compiler has to be kept from moving them (a fence would also wait for the
                 // global stores in flight)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                constexpr int VS = WAVE / EPL;                   // vectors per instruction
-                const int g = lane / EPL, e = lane % EPL;
-                char *tab_e = reinterpret_cast<char *>(s_tab) + 4 * e;
+                // one 64-bit LDS add carries TWO byte sums (the low sum cannot carry into the high one: a
+                // workgroup adds at most 1024 x 255 to it): lanes = VS vectors x DP2 element pairs
+                constexpr int VS = WAVE / DP2;                   // vectors per instruction
+                const int g = lane / DP2, pr = lane % DP2;
+                char *tab_p = reinterpret_cast<char *>(s_tab) + 8 * pr;
                 constexpr int STEPS = (WAVE + VS - 1) / VS;
-                if (d == EPL && WAVE % EPL == 0) {             // (uniform) every lane has work in every step
 #pragma unroll
-                    for (int j = 0; j < STEPS; ++j) {
-                        const int src = j * VS + g;
-                        atomicAdd(reinterpret_cast<uint32_t *>(tab_e + st_lbl[src]), (uint32_t)st_rows[src * EPL + e]);
-                    }
-                } else {                                       // padded rows, or EPL does not divide the wave
-#pragma unroll
-                    for (int j = 0; j < STEPS; ++j) {
-                        const int src = j * VS + g;
-                        const bool on = g < VS && src < WAVE && e < d;
-                        const int srcc = on ? src : 0;
-                        const int off = st_lbl[srcc];
-                        const uint32_t b = st_rows[srcc * EPL + e];
-                        if (on) atomicAdd(reinterpret_cast<uint32_t *>(tab_e + off), b);
-                    }
+                for (int j = 0; j < STEPS; ++j) {
+                    const int src = j * VS + g;
+                    const bool on = (WAVE % DP2 == 0) || (g < VS && src < WAVE);   // (DP2 divides the wave: always)
+                    const int srcc = on ? src : 0;
+                    const int off = st_lbl[srcc];
+                    const uint32_t two = *reinterpret_cast<const uint16_t *>(st_rows + srcc * EPL + 2 * pr);
+                    const unsigned long long v = (unsigned long long)(two & 0xffu) | ((unsigned long long)(two >> 8) << 32);
+                    if (on) atomicAdd(reinterpret_cast<unsigned long long *>(tab_p + off), v);
                 }
-                atomicAdd(&s_tab[(settled ? idx : K) * (d + 1) + d], 1u);
+                atomicAdd(&s_tab[(settled ? idx : K) * TROW + EPL], 1u);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging area is rewritten by the next group
             }
             if (!settled) continue;
@@ -1406,10 +1496,11 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
     }
     if (ACC) {
         __syncthreads();
-        unsigned long long *rep = a.acc_rep + (size_t)(blockIdx.x % NREP) * tabn;
+        unsigned long long *rep = a.acc_rep + (size_t)(blockIdx.x % NREP) * (K * (d + 1));
         for (int i = tid; i < tabn; i += BLOCK) {
             const uint32_t v = s_tab[i];
-            if (v) atomicAdd(&rep[i], (unsigned long long)v);
+            const int kk = i / TROW, e = i - kk * TROW;            // replica rows are [d sums | count]
+            if (v && (e < d || e == EPL)) atomicAdd(&rep[kk * (d + 1) + (e < d ? e : d)], (unsigned long long)v);
         }
     }
 }
@@ -1417,7 +1508,8 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
 // Adds the NREP replica tables of the fused accumulation into the caller's sums / counts.
 __global__ __launch_bounds__(256) void k_reduce_replicas(const unsigned long long *__restrict__ rep, int K, int d,
                                                          unsigned long long *__restrict__ sums,
-                                                         unsigned long long *__restrict__ counts) {
+                                                         unsigned long long *__restrict__ counts, Gate gate) {
+    if (gate_closed(gate)) return;
     const int tabn = K * (d + 1);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= tabn) return;
@@ -1443,8 +1535,9 @@ __global__ __launch_bounds__(1024) void k_fixup(const uint8_t *__restrict__ bloc
                                                 const uint32_t *__restrict__ qcount, uint32_t qcap,
                                                 int32_t *__restrict__ labels, double *__restrict__ min_dist,
                                                 unsigned long long *__restrict__ sums,
-                                                unsigned long long *__restrict__ counts) {
+                                                unsigned long long *__restrict__ counts, Gate gate) {
     extern __shared__ __align__(16) double s_cbT[];
+    if (gate_closed(gate)) return;
     const int lane = threadIdx.x & (WAVE - 1);
     const uint32_t waves_per_wg = blockDim.x >> 6;
     const uint32_t wave = blockIdx.x * waves_per_wg + (threadIdx.x >> 6);
@@ -1510,10 +1603,10 @@ __global__ __launch_bounds__(1024) void k_fixup(const uint8_t *__restrict__ bloc
 
 // The fix-up pass with the element-sum bound of the pruned search (needs the sorted fixed-point
 // codebook that k_prepare leaves for K <= PREP_SORT_CAP).  A wave takes one queued vector: lanes hold
-// 64 consecutive positions of the sorted codebook, starting with the chunk around the vector's own
-// element sum; after every chunk the exact best distance D gives the range of positions that can
-// still hold a codeword at distance <= D (their fixed-point element sum lies within
-// D * 2^s + Emax + 1 of the vector's, looked up in postab), and the wave takes the next chunk on
+// 256 consecutive positions of the sorted codebook (four per lane), starting with those around the
+// vector's own element sum; after every pass the exact best distance D gives the range of positions
+// that can still hold a codeword at distance <= D (their fixed-point element sum lies within
+// D * 2^s + Emax + 1 of the vector's, looked up in postab), and the wave takes the next 256 on
 // whichever side is not covered yet.  A skipped codeword is strictly further away than the winner,
 // so label and distance equal those of the full search, ties included (lowest codeword index).
 template <bool LDS_CB>
@@ -1523,12 +1616,12 @@ __global__ __launch_bounds__(1024) void k_fixup_pruned(const uint8_t *__restrict
                                                        const uint32_t *__restrict__ queue,
                                                        const uint32_t *__restrict__ qcount, uint32_t qcap,
                                                        const PrepHeader *__restrict__ hdr,
-                                                       const uint32_t *__restrict__ bias,
-                                                       const uint32_t *__restrict__ postab,
+                                                       const uint32_t *bias, const uint32_t *postab,
                                                        int32_t *__restrict__ labels, double *__restrict__ min_dist,
                                                        unsigned long long *__restrict__ sums,
-                                                       unsigned long long *__restrict__ counts) {
+                                                       unsigned long long *__restrict__ counts, Gate gate) {
     extern __shared__ __align__(16) double s_cbT[];
+    if (gate_closed(gate)) return;
     const int lane = threadIdx.x & (WAVE - 1);
     const uint32_t waves_per_wg = blockDim.x >> 6;
     const uint32_t wave = blockIdx.x * waves_per_wg + (threadIdx.x >> 6);
@@ -1541,73 +1634,117 @@ __global__ __launch_bounds__(1024) void k_fixup_pruned(const uint8_t *__restrict
         any = any || qcount[16 * (ww & (NQ - 1))] > ww / NQ;
     }
     if (!any) return;
+    // LDS_CB: the transposed codebook, the position table and the position -> codeword map are staged in LDS,
+    // so that a queued vector costs no memory round trip beyond fetching the vector itself
+    const uint32_t *s_postab = reinterpret_cast<const uint32_t *>(s_cbT + (size_t)K * d);
+    const uint32_t *s_bias = s_postab + POSTAB_WORDS;
     if (LDS_CB) {
         const int n = K * d;
         for (int i = threadIdx.x; i < n; i += blockDim.x) s_cbT[i] = cbT[i];
+        uint32_t *wp = reinterpret_cast<uint32_t *>(s_cbT + (size_t)K * d);
+        for (int i = threadIdx.x; i < POSTAB_WORDS; i += blockDim.x) wp[i] = postab[i];
+        for (int i = threadIdx.x; i < K; i += blockDim.x) wp[POSTAB_WORDS + i] = bias[i];
         __syncthreads();
+        postab = s_postab;
+        bias = s_bias;
     }
     const uint32_t shift = hdr->shift, emax = hdr->emax, tshift = hdr->tshift, nt = hdr->nt;
     const double scale = (double)(1u << shift);
-    const int kchunks = (K + WAVE - 1) / WAVE;                  // chunks of 64 sorted positions
     const uint32_t count = qcount[16 * sub];
     queue += (size_t)sub * qcap;
-    for (uint32_t i0 = rank; i0 < count; i0 += nwaves) {
-        int64_t nrow = (int64_t)queue[i0];                      // wave-uniform
+    // queue entry -> row position, vector index, lane's row byte and the lane's share of the element sum
+    // (three dependent memory round trips); the next item's are requested while the current one is searched
+    auto fetch = [&](uint32_t i, int64_t &nrow, int64_t &nout, uint32_t &xv, uint32_t &part) {
+        nrow = (int64_t)queue[i < count ? i : count - 1];       // wave-uniform
         nrow = nrow < N ? nrow : N - 1;
-        int64_t n = nrow;                                       // vector index the results are written at
+        nout = nrow;                                            // vector index the results are written at
         if (perm) {                                             // `blocks` is the sorted copy: origin inside the window
-            n = (nrow & ~(int64_t)(SORT_WIN - 1)) + (int64_t)perm[nrow];
-            n = n < N ? n : N - 1;
+            nout = (nrow & ~(int64_t)(SORT_WIN - 1)) + (int64_t)perm[nrow];
+            nout = nout < N ? nout : N - 1;
         }
+        const uint8_t *xr = blocks + (size_t)nrow * d;
+        xv = lane < d ? (uint32_t)xr[lane] : 0u;
+        part = xv;
+        for (int e = lane + WAVE; e < d; e += WAVE) part += xr[e];
+    };
+    int64_t nrow_next = 0, n_next = 0;
+    uint32_t xv_next = 0, part_next = 0;
+    if (rank < count) fetch(rank, nrow_next, n_next, xv_next, part_next);
+    for (uint32_t i0 = rank; i0 < count; i0 += nwaves) {
+        const int64_t nrow = nrow_next, n = n_next;
+        const uint32_t xv0 = xv_next;
+        uint32_t part = part_next;
+        fetch(i0 + nwaves, nrow_next, n_next, xv_next, part_next);
         const uint8_t *xrow = blocks + (size_t)nrow * d;
         // element sum of the vector in the fixed-point units of the codebook rows
-        uint32_t part = 0;
-        for (int e = lane; e < d; e += WAVE) part += xrow[e];
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, WAVE);
         const uint32_t sx = part << shift;
-        const uint32_t xv0 = lane < d ? (uint32_t)xrow[lane] : 0u;
         double best = __builtin_huge_val();
         int bidx = 0x7fffffff;
-        // one chunk: lane's position p -> codeword bias[p]; its exact distance in sequential fp64
-        auto chunk = [&](int c) {
-            const int p = c * WAVE + lane;
-            const int k = (int)(bias[p < K ? p : K - 1] & 0x7fffffffu);      // clamped: loads stay in bounds
-            double acc = 0.0;
+        // one pass: 256 consecutive positions of the sorted codebook from p0 on (lane's positions p0 + 64 q +
+        // lane, q = 0 .. 3; those outside [0, K) do not count), codeword bias[p], exact distance in
+        // sequential fp64.  Loads are issued eight elements x four codewords at a time; the additions
+        // stay in element order, one chain per codeword.
+        auto pass = [&](int p0) {
+            int kk[4], pp[4];                                   // codeword index; (clamped) sorted position
+            bool on[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int pq = p0 + q * WAVE + lane;
+                on[q] = pq >= 0 && pq < K;
+                pp[q] = pq < 0 ? 0 : (pq < K ? pq : K - 1);       // clamped: loads stay in bounds
+                kk[q] = (int)(bias[pp[q]] & 0x7fffffffu);
+            }
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
             for (int ebase = 0; ebase < d; ebase += WAVE) {
                 const int ecount = d - ebase < WAVE ? d - ebase : WAVE;
                 uint32_t xv = xv0;
                 if (ebase > 0) xv = lane < ecount ? (uint32_t)xrow[ebase + lane] : 0u;
-                // loads eight elements ahead of the additions that use them (the additions stay in element order)
                 int e0 = 0;
                 for (; e0 + 8 <= ecount; e0 += 8) {
-                    double c[8];
+                    double c[8][4];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const size_t off = (size_t)(ebase + e0 + j) * K + k;
-                        c[j] = LDS_CB ? s_cbT[off] : cbT[off];
+                        const size_t off = (size_t)(ebase + e0 + j) * K;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) c[j][q] = LDS_CB ? s_cbT[off + pp[q]] : cbT[off + pp[q]];
                     }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc += fabs((double)__builtin_amdgcn_readlane(xv, e0 + j) - c[j]);
+                    for (int j = 0; j < 8; ++j) {
+                        const double xe = (double)__builtin_amdgcn_readlane(xv, e0 + j);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[q] += fabs(xe - c[j][q]);
+                    }
                 }
                 for (; e0 < ecount; ++e0) {
-                    const size_t off = (size_t)(ebase + e0) * K + k;
+                    const size_t off = (size_t)(ebase + e0) * K;
                     const double xe = (double)__builtin_amdgcn_readlane(xv, e0);
-                    acc += fabs(xe - (LDS_CB ? s_cbT[off] : cbT[off]));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] += fabs(xe - (LDS_CB ? s_cbT[off + pp[q]] : cbT[off + pp[q]]));
                 }
             }
-            double cd = p < K ? acc : __builtin_huge_val();
-            int ci = p < K ? k : 0x7fffffff;
+            double cd = __builtin_huge_val();
+            int ci = 0x7fffffff;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (on[q] && (acc[q] < cd || (acc[q] == cd && kk[q] < ci))) {
+                    cd = acc[q];
+                    ci = kk[q];
+                }
+            }
             wave_argmin(cd, ci);                                // lexicographic (distance, codeword index)
             if (cd < best || (cd == best && ci < bidx)) {
                 best = cd;
                 bidx = ci;
             }
         };
-        int ca = (int)(postab[sx >> tshift] / WAVE);
-        if (ca >= kchunks) ca = kchunks - 1;
-        int cb_ = ca + 1;                                       // chunks [ca, cb_) are done after the first call
-        chunk(ca);
+        constexpr int PASS = 4 * WAVE;
+        int lo_done = (int)postab[sx >> tshift] - PASS / 2;     // first pass: the 256 positions around the vector's sum
+        if (lo_done > K - PASS) lo_done = K - PASS;
+        if (lo_done < 0) lo_done = 0;
+        int hi_done = lo_done + PASS;
+        pass(lo_done);
         for (;;) {
             // positions that can still hold a codeword no further away than `best`
             const double t = ceil(best * scale) + (double)emax + 1.0;
@@ -1617,9 +1754,15 @@ __global__ __launch_bounds__(1024) void k_fixup_pruned(const uint8_t *__restrict
             if (ih > nt + 1ull) ih = nt + 1ull;
             const int klo = (int)postab[lo_sum >> tshift];
             const int khi = (int)postab[ih];
-            if (klo < ca * WAVE) chunk(--ca);
-            else if (khi > cb_ * WAVE) chunk(cb_++);
-            else break;
+            if (klo < lo_done) {
+                lo_done -= PASS;
+                pass(lo_done);
+            } else if (khi > hi_done) {
+                pass(hi_done);
+                hi_done += PASS;
+            } else {
+                break;
+            }
         }
         if (lane == 0) {
             labels[n] = bidx;
@@ -1778,7 +1921,9 @@ __global__ __launch_bounds__(1024) void k_npsum_final(const double *__restrict__
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_assign_exact(const uint8_t *__restrict__ blocks, int64_t N, int d,
                                                       const double *__restrict__ cb, int K,
-                                                      int32_t *__restrict__ labels, double *__restrict__ min_dist) {
+                                                      int32_t *__restrict__ labels, double *__restrict__ min_dist,
+                                                      Gate gate) {
+    if (gate_closed(gate)) return;
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
         const uint8_t *x = blocks + (size_t)n * d;
         double best = __builtin_huge_val();
@@ -1805,7 +1950,8 @@ __global__ __launch_bounds__(256) void k_accum_rows(const uint8_t *__restrict__ 
                                                     const uint16_t *__restrict__ perm, int64_t N, int d,
                                                     const int32_t *__restrict__ labels, int K,
                                                     unsigned long long *__restrict__ sums,
-                                                    unsigned long long *__restrict__ counts) {
+                                                    unsigned long long *__restrict__ counts, Gate gate) {
+    if (gate_closed(gate)) return;
     const int lane = threadIdx.x & (WAVE - 1);
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -1845,8 +1991,9 @@ __global__ __launch_bounds__(512) void k_accum_dist(const uint8_t *__restrict__ 
                                                     const double *__restrict__ cb, int K,
                                                     unsigned long long *__restrict__ sums,
                                                     unsigned long long *__restrict__ counts,
-                                                    double *__restrict__ min_dist) {
+                                                    double *__restrict__ min_dist, Gate gate) {
     extern __shared__ __align__(16) uint32_t s_acc[];
+    if (gate_closed(gate)) return;
     const int tid = threadIdx.x;
     const int tabn = K * (d + 1);
     const double *s_cb = reinterpret_cast<const double *>(s_acc + ((tabn + 3) & ~3));
@@ -2314,7 +2461,7 @@ bool prune_supported(int K, int d) {
 // LDS bytes of the fused accumulation (table + per-wave staging) for a 256-thread workgroup.
 size_t fused_acc_lds(int K, int d) {
     const int dp2 = dp2_bucket(d);
-    return ((size_t)(K + 1) * (d + 1) + 3) / 4 * 16 + (size_t)4 * (WAVE * 2 * dp2 + WAVE * 4);
+    return ((size_t)(K + 1) * (2 * dp2 + 2) + 3) / 4 * 16 + (size_t)4 * (WAVE * 2 * dp2 + WAVE * 4);
 }
 
 // Whether run_fast can accumulate sums / counts itself (pruned kernel, table within a quarter of the LDS).
@@ -2342,7 +2489,7 @@ int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int
     uint32_t *qcount = reinterpret_cast<uint32_t *>(w + LN.qcount);
     uint32_t *queue = reinterpret_cast<uint32_t *>(w + LN.queue);
     const bool do_filter = (phases & 1) != 0, do_fixup = (phases & 2) != 0;
-    if (do_filter) HIP_TRY(hipMemsetAsync(qcount, 0, (size_t)NQ * 64, st));
+    if (do_filter && !g_ws_zeroed) HIP_TRY(hipMemsetAsync(qcount, 0, (size_t)NQ * 64, st));
     const uint32_t qcap = (uint32_t)queue_cap(N);
 
     DeviceInfo di;
@@ -2373,12 +2520,13 @@ int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int
     a.acc_rep = nullptr;
     if (sums) {
         a.acc_rep = reinterpret_cast<unsigned long long *>(w + L.acc_rep);
-        HIP_TRY(hipMemsetAsync(a.acc_rep, 0, (size_t)NREP * K * (d + 1) * 8, st));
+        if (!g_ws_zeroed) HIP_TRY(hipMemsetAsync(a.acc_rep, 0, (size_t)NREP * K * (d + 1) * 8, st));
     }
     a.ntiles = ntiles;
     a.vec4 = ((d & 3) == 0) && ((reinterpret_cast<uintptr_t>(blocks) & 3) == 0);
     if (d == 16 && (reinterpret_cast<uintptr_t>(blocks) & 15) == 0) a.vec4 = 2;     // whole 16-byte rows
     a.rows = nullptr; a.perm = nullptr; a.shdr = nullptr;
+    a.gate = g_gate;
     a.postab = reinterpret_cast<const uint32_t *>(w + L.postab);
     if (prune) {
         SortedLayout SL = sorted_layout(d, N);
@@ -2414,19 +2562,20 @@ int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int
     // fix-up: a fixed grid strides over the sub-queues (their lengths are only known on the device);
     // small codebooks are staged in LDS, one 1024-thread workgroup per CU
     const size_t cb_bytes = (size_t)K * d * sizeof(double);
-    // Larger codebooks: the fix-up applies the element-sum bound too (needs the sorted codebook); small
-    // ones are cheaper to scan whole with four queue items in flight per wave.
-    if (K >= VQ_FIXUP_PRUNE_MIN_K && K <= PREP_SORT_CAP) {
+    // Codebooks that k_prepare sorted by element sum (their transposed fp64 copy is in sorted order too) take
+    // the fix-up with the element-sum bound; larger ones are scanned whole.
+    if (K <= PREP_SORT_CAP) {
         const uint32_t *postab = reinterpret_cast<const uint32_t *>(w + L.postab);
+        const size_t fx_lds = cb_bytes + (size_t)(POSTAB_WORDS + K) * 4;     // codebook, position table, position map
         if (cb_bytes <= 128 * 1024) {
-            if (cb_bytes > 48 * 1024)
+            if (fx_lds > 48 * 1024)
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fixup_pruned<true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)cb_bytes));
-            hipLaunchKernelGGL(k_fixup_pruned<true>, dim3((di.cus + 3) / 4 * 4), dim3(1024), cb_bytes, st, fx_rows, fx_perm, N, d,
-                               cbT, K, queue, qcount, qcap, hdr, bias, postab, labels, min_dist, sums, counts);
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)fx_lds));
+            hipLaunchKernelGGL(k_fixup_pruned<true>, dim3((di.cus + 3) / 4 * 4), dim3(1024), fx_lds, st, fx_rows, fx_perm, N, d,
+                               cbT, K, queue, qcount, qcap, hdr, bias, postab, labels, min_dist, sums, counts, g_gate);
         } else {
             hipLaunchKernelGGL(k_fixup_pruned<false>, dim3((di.cus * 4 + 15) / 16 * 16), dim3(256), 0, st, fx_rows, fx_perm, N, d,
-                               cbT, K, queue, qcount, qcap, hdr, bias, postab, labels, min_dist, sums, counts);
+                               cbT, K, queue, qcount, qcap, hdr, bias, postab, labels, min_dist, sums, counts, g_gate);
         }
         LAUNCH_CHECK("k_fixup_pruned");
     } else if (cb_bytes <= 64 * 1024) {
@@ -2434,15 +2583,15 @@ int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fixup<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)cb_bytes));
         hipLaunchKernelGGL(k_fixup<true>, dim3((di.cus + 3) / 4 * 4), dim3(1024), cb_bytes, st, fx_rows, fx_perm, N, d, cbT,
-                           K, queue, qcount, qcap, labels, min_dist, sums, counts);
+                           K, queue, qcount, qcap, labels, min_dist, sums, counts, g_gate);
     } else {
         hipLaunchKernelGGL(k_fixup<false>, dim3((di.cus * 4 + 15) / 16 * 16), dim3(256), 0, st, fx_rows, fx_perm, N, d, cbT, K,
-                           queue, qcount, qcap, labels, min_dist, sums, counts);
+                           queue, qcount, qcap, labels, min_dist, sums, counts, g_gate);
     }
     LAUNCH_CHECK("k_fixup");
     if (sums) {
         hipLaunchKernelGGL(k_reduce_replicas, dim3((K * (d + 1) + 255) / 256), dim3(256), 0, st, a.acc_rep, K, d, sums,
-                           counts);
+                           counts, g_gate);
         LAUNCH_CHECK("k_reduce_replicas");
     }
     return VQ_OK;
@@ -2476,7 +2625,7 @@ int run_accum(const uint8_t *blocks, const uint16_t *perm, int64_t N, int d, con
         if (lds > 48 * 1024)                                                                                           \
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                          \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(ACC_BLOCK), lds, st, blocks, perm, N, d, labels, cb, K, sums, counts, min_dist); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(ACC_BLOCK), lds, st, blocks, perm, N, d, labels, cb, K, sums, counts, min_dist, g_gate); \
     } while (0)
         if (vec16 && cb_lds) VQ_LAUNCH_ACCUM(true, true);
         else if (vec16) VQ_LAUNCH_ACCUM(true, false);
@@ -2488,7 +2637,7 @@ int run_accum(const uint8_t *blocks, const uint16_t *perm, int64_t N, int d, con
     }
     const int V = d >= WAVE ? 1 : WAVE / d;
     hipLaunchKernelGGL(k_accum_rows, dim3(grid_for((N + V - 1) / V, 4, 16384)), dim3(256), 0, st, blocks, perm, N, d, labels,
-                       K, sums, counts);
+                       K, sums, counts, g_gate);
     LAUNCH_CHECK("k_accum_rows");
     return VQ_OK;
 }
@@ -2639,7 +2788,7 @@ int vq_encode_l1(const uint8_t *blocks, int64_t N, int d, const double *cb, int 
         return run_fast(blocks, nullptr, 0, N, d, cb, K, labels, min_dist, nullptr, nullptr, ws, st);
     }
     int grid = grid_for(N, 256, 16384);
-    hipLaunchKernelGGL(k_assign_exact, dim3(grid), dim3(256), 0, st, blocks, N, d, cb, K, labels, min_dist);
+    hipLaunchKernelGGL(k_assign_exact, dim3(grid), dim3(256), 0, st, blocks, N, d, cb, K, labels, min_dist, g_gate);
     LAUNCH_CHECK("k_assign_exact");
     return VQ_OK;
 }
@@ -2671,7 +2820,7 @@ int vq_encode_l1_static(const uint8_t *blocks, int64_t N, int d, const double *c
     }
     // the all-fp64 search keeps everything in registers: no scratch at all
     int grid = grid_for(N, 256, 16384);
-    hipLaunchKernelGGL(k_assign_exact, dim3(grid), dim3(256), 0, st, blocks, N, d, cb, K, labels, min_dist);
+    hipLaunchKernelGGL(k_assign_exact, dim3(grid), dim3(256), 0, st, blocks, N, d, cb, K, labels, min_dist, g_gate);
     LAUNCH_CHECK("k_assign_exact");
     return VQ_OK;
 }
@@ -2835,7 +2984,7 @@ int vq_lbg_accum(const uint8_t *blocks, const void *sorted, size_t sorted_bytes,
             }
         } else {
             int grid = grid_for(N, 256, 16384);
-            hipLaunchKernelGGL(k_assign_exact, dim3(grid), dim3(256), 0, st, blocks, N, d, cb, K, labels, min_dist);
+            hipLaunchKernelGGL(k_assign_exact, dim3(grid), dim3(256), 0, st, blocks, N, d, cb, K, labels, min_dist, g_gate);
             LAUNCH_CHECK("k_assign_exact");
             rc = run_accum(blocks, nullptr, N, d, labels, cb, K, s64, c64, nullptr, st);
             if (rc) return rc;
@@ -2844,6 +2993,78 @@ int vq_lbg_accum(const uint8_t *blocks, const void *sorted, size_t sorted_bytes,
     double *cs = chunk_sums ? chunk_sums
                             : reinterpret_cast<double *>(static_cast<char *>(ws) + ws_layout(K, d, N).chunks);
     return run_numpy_sum(min_dist, N, cs, dist_sum, st);
+}
+
+size_t vq_lbg_state_bytes(int max_iterations) {
+    if (max_iterations < 1) return 0;
+    return align_up(offsetof(LbgState, rec) + (size_t)max_iterations * sizeof(LbgRecord), 256);
+}
+
+int vq_lbg_stage_begin(void *state, size_t state_bytes, int max_iterations, void *stream) {
+    if (!state) return fail(VQ_E_INVALID, "null state pointer");
+    if (max_iterations < 1) return fail(VQ_E_INVALID, "need max_iterations >= 1");
+    if (state_bytes < vq_lbg_state_bytes(max_iterations))
+        return fail(VQ_E_WORKSPACE, "state of %zu bytes needed, %zu given", vq_lbg_state_bytes(max_iterations), state_bytes);
+    hipLaunchKernelGGL(k_lbg_stage_begin, dim3((max_iterations + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<LbgState *>(state), max_iterations);
+    LAUNCH_CHECK("k_lbg_stage_begin");
+    return VQ_OK;
+}
+
+int vq_lbg_iterate(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d, double *cb, int K,
+                   int64_t n_total, double threshold, int iteration, uint64_t *sums, uint64_t *counts, int32_t *labels,
+                   double *min_dist, int mode, void *state, size_t state_bytes, void *ws, size_t ws_bytes, void *stream) {
+    if (!state) return fail(VQ_E_INVALID, "null state pointer");
+    if (iteration < 0 || state_bytes < vq_lbg_state_bytes(iteration + 1))
+        return fail(VQ_E_INVALID, "iteration %d is outside the state buffer (%zu bytes)", iteration, state_bytes);
+    if (n_total < 1 || N > n_total) return fail(VQ_E_INVALID, "need n_total >= max(N, 1)");
+    if (!sums || !counts || !cb) return fail(VQ_E_INVALID, "null sums, counts or codebook pointer");
+    if (K <= 0 || d <= 0) return fail(VQ_E_INVALID, "need K > 0 and d > 0");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    LbgState *S = static_cast<LbgState *>(state);
+    struct GateScope {                                        // the launches below carry this iteration's gate
+        GateScope(const int32_t *p, int it) { g_gate = Gate{p, it}; }
+        ~GateScope() { g_gate = Gate{nullptr, 0}; }
+    } scope(&S->stopped_after, iteration);
+    int rc = check_ws(ws, ws_bytes, K, d, N);
+    if (rc) return rc;
+    // one launch zeroes the caller's sums and counts, the queue counters and the replica tables of the workspace
+    // (regions that are not 16-byte multiples fall back to plain fills)
+    struct ZeroScope {
+        ~ZeroScope() { g_ws_zeroed = false; }
+    } zscope;
+    {
+        const WsLayout L0 = ws_layout(K, d, 0), LN = ws_layout(K, d, N);
+        char *w = static_cast<char *>(ws);
+        const size_t rep_bytes = LN.cbT - LN.acc_rep;              // 0 when this shape has no replica tables
+        void *ptrs[4] = {sums, counts, w + LN.qcount, w + L0.acc_rep};
+        size_t bytes[4] = {sizeof(uint64_t) * (size_t)K * d, sizeof(uint64_t) * (size_t)K, (size_t)NQ * 64, rep_bytes};
+        bool ok = true;
+        for (int r = 0; r < 4; ++r) ok = ok && (reinterpret_cast<uintptr_t>(ptrs[r]) % 16 == 0) && (bytes[r] % 16 == 0);
+        if (ok) {
+            ZeroRegions z;
+            size_t most = 0;
+            for (int r = 0; r < 4; ++r) {
+                z.p[r] = static_cast<uint4 *>(ptrs[r]);
+                z.n16[r] = bytes[r] / 16;
+                most = z.n16[r] > most ? z.n16[r] : most;
+            }
+            hipLaunchKernelGGL(k_zero_regions, dim3(grid_for((int64_t)most, 256, 1024)), dim3(256), 0, st, z);
+            LAUNCH_CHECK("k_zero_regions");
+            g_ws_zeroed = true;
+        } else {
+            HIP_TRY(hipMemsetAsync(sums, 0, bytes[0], st));
+            HIP_TRY(hipMemsetAsync(counts, 0, bytes[1], st));
+        }
+    }
+    rc = vq_lbg_accum(blocks, sorted, sorted_bytes, N, d, cb, K, sums, counts, labels, min_dist, &S->dist_sum, nullptr,
+                          mode, ws, ws_bytes, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_finalize_rule, dim3(grid_for((int64_t)K * d, 256, 4096)), dim3(256), 0, st,
+                       reinterpret_cast<const unsigned long long *>(sums),
+                       reinterpret_cast<const unsigned long long *>(counts), cb, K, d, (double)n_total, threshold, S, g_gate);
+    LAUNCH_CHECK("k_finalize_rule");
+    return VQ_OK;
 }
 
 int vq_lbg_finalize(const uint64_t *sums, const uint64_t *counts, const double *cb_old, int K, int d, double *cb_new,

@@ -41,6 +41,8 @@ class HipEngine:
         self._scratch_n = -1
         self._labels_scratch = None
         self._dist_scratch = None
+        self._side = None
+        self._pinned = None
 
     # -- plumbing ----------------------------------------------------------------------------
     def _stream(self):
@@ -240,6 +242,73 @@ class HipEngine:
         if want_chunks:
             out.append(chunks[: -(-N // 8192)])
         return tuple(out)
+
+    # -- one whole split stage with the stop rule on the device (VQ_Full.py:76-98) ----------------------
+    def _mark(self):
+        """An event on the engine's stream, recorded now."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return ev
+
+    def _read_bytes(self, buf, off, nbytes, mark):
+        """nbytes of a device uint8 buffer as numpy, as they are once the work before `mark` has finished;
+        work enqueued after the mark keeps running (the copy goes through a side stream)."""
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._pinned = torch.empty(256, dtype=torch.uint8).pin_memory()
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(mark)
+            self._pinned[:nbytes].copy_(buf[off: off + nbytes], non_blocking=True)
+            self._side.synchronize()
+        return self._pinned[:nbytes].numpy().copy()
+
+    def lbg_stage(self, blocks, cb, n_total, threshold, limit, sorted=None, shape=None, mode=None):
+        """All iterations of one split stage.  Iteration j + 1 is enqueued before the outcome of iteration j is
+        read, so the GPU never waits for the host; the stop rule is evaluated on the device and gates the
+        iterations enqueued past it.  threshold < 0: run exactly `limit` iterations.
+        Returns (codebook after the stage, [distortion of every iteration run], index of the iteration that met
+        the rule or -1)."""
+        import numpy as np
+        N, d = blocks.shape if blocks is not None else shape
+        cb = self._dev(cb, torch.float64).clone()              # updated in place by every iteration
+        K = cb.shape[0]
+        if limit < 1:
+            return cb, [], -1
+        nstate = lib.vq_lbg_state_bytes(int(limit))
+        state = torch.empty(nstate, dtype=torch.uint8, device=self.device)
+        acc = torch.empty(K * d + K, dtype=torch.int64, device=self.device)
+        if self._scratch_n < N:
+            self._labels_scratch = torch.empty(N, dtype=torch.int32, device=self.device)
+            self._dist_scratch = torch.empty(N, dtype=torch.float64, device=self.device)
+            self._scratch_n = N
+        ws = self._workspace(K, d, N)
+        use_mode = self.mode if mode is None else mode
+        with torch.cuda.device(self.device):
+            check(lib.vq_lbg_stage_begin(_ptr(state), nstate, int(limit), self._stream()), "vq_lbg_stage_begin")
+
+        def enqueue(j):
+            with torch.cuda.device(self.device):
+                check(lib.vq_lbg_iterate(_ptr(blocks), _ptr(sorted), _nbytes(sorted), N, d, _ptr(cb), K, int(n_total),
+                                         float(threshold), j, _ptr(acc[: K * d]), _ptr(acc[K * d:]),
+                                         _ptr(self._labels_scratch), _ptr(self._dist_scratch), use_mode, _ptr(state),
+                                         nstate, _ptr(ws), ws.numel(), self._stream()), "vq_lbg_iterate")
+            return self._mark()
+
+        distortions, conv = [], -1
+        mark = enqueue(0)
+        for j in range(limit):
+            nxt = enqueue(j + 1) if j + 1 < limit else None
+            rec = self._read_bytes(state, 64 + 16 * j, 16, mark)
+            mark = nxt
+            D = float(np.frombuffer(rec[:8].tobytes(), dtype=np.float64)[0])
+            converged, valid = (int(v) for v in np.frombuffer(rec[8:16].tobytes(), dtype=np.uint32))
+            if not valid:
+                break
+            distortions.append(D)
+            if converged:
+                conv = j
+                break
+        return cb, distortions, conv
 
     def numpy_sum(self, v):
         """Sum of a float64 vector in numpy's summation order (np.add.reduce), on the device."""

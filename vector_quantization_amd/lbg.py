@@ -153,7 +153,7 @@ def lbg_iteration(engine, blocks, cb, n_total, group=None, shard_info=None, sort
 
 
 def train_lbg(engine, blocks, k, epsilon=0.01, threshold=0.001, max_iterations=100, group=None, log=print,
-              iters_per_stage=None, on_converged=None, sorted=None):
+              iters_per_stage=None, on_converged=None, sorted=None, shape=None):
     """Follows VQ_Full.py:60-98.
 
     blocks: this rank's (N_local, d) uint8 shard on the engine's device.  group: a
@@ -179,21 +179,34 @@ def train_lbg(engine, blocks, k, epsilon=0.01, threshold=0.001, max_iterations=1
         done, conv_i = 0, -1
         forced = None if iters_per_stage is None else int(iters_per_stage[stage])
         limit = max_iterations if forced is None else forced
-        for i in range(limit):
-            cb, distortion = lbg_iteration(engine, blocks, cb, n_total, group, shard_info, sorted)
-            distortions.append(distortion)
-            done += 1
-            if forced is None and prev != float("inf"):
-                # prev == 0 gives nan (or inf), which never satisfies the test -- as in the reference
-                change = abs(prev - distortion) / prev if prev != 0.0 else float("nan")
-                if change < threshold:
-                    conv_i = i
-                    if on_converged is not None:
-                        on_converged(int(cb.shape[0]), i, distortion)
-                    elif log is not None:
-                        log(f"Converged at iter {i}, distortion={distortion:.3f}")
-                    break
-            prev = distortion
+        if group is None and hasattr(engine, "lbg_stage"):
+            # one GPU: the stage runs with the stop rule on the device, iterations enqueued ahead of the host
+            n_d = None if blocks is not None else shape
+            cb, stage_d, conv_i = engine.lbg_stage(blocks, cb, n_total, -1.0 if forced is not None else threshold, limit,
+                                                   sorted=sorted, shape=n_d)
+            distortions.extend(stage_d)
+            done = len(stage_d)
+            if conv_i >= 0:
+                if on_converged is not None:
+                    on_converged(int(cb.shape[0]), conv_i, stage_d[-1])
+                elif log is not None:
+                    log(f"Converged at iter {conv_i}, distortion={stage_d[-1]:.3f}")
+        else:
+            for i in range(limit):
+                cb, distortion = lbg_iteration(engine, blocks, cb, n_total, group, shard_info, sorted)
+                distortions.append(distortion)
+                done += 1
+                if forced is None and prev != float("inf"):
+                    # prev == 0 gives nan (or inf), which never satisfies the test -- as in the reference
+                    change = abs(prev - distortion) / prev if prev != 0.0 else float("nan")
+                    if change < threshold:
+                        conv_i = i
+                        if on_converged is not None:
+                            on_converged(int(cb.shape[0]), i, distortion)
+                        elif log is not None:
+                            log(f"Converged at iter {i}, distortion={distortion:.3f}")
+                        break
+                prev = distortion
         iters.append(done)
         conv.append(conv_i)
         stage += 1
