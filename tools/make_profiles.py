@@ -1,17 +1,18 @@
 #!/usr/bin/env python3
-"""Copies the rocprofv3 outputs of tools/gpu_round.sh and tools/gpu_pmc.sh from gpurun_out/ into
-profiles/ (filtered to this library's kernels) and derives the per-kernel PMC table and the summary
-bench.py reads.  Usage: python3 tools/make_profiles.py r01"""
+"""Copies the rocprofv3 outputs of tools/gpu_round.sh from gpurun_out/ into profiles/ (filtered to this
+library's kernels) and derives the per-kernel PMC table and the summary bench.py reads.
+Usage: python3 tools/make_profiles.py r02"""
 import collections
 import csv
 import glob
+import hashlib
 import json
 import os
 import shutil
 import statistics
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 src = os.path.join(root, "gpurun_out")
@@ -22,36 +23,48 @@ def short(name):
     return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
 
 
-# ---- bench line + kernel trace of the same command ------------------------------------------------
+def is_ours(name):
+    return short(name).startswith("k_")
+
+
+lib_sha = hashlib.sha256(open(os.path.join(root, "vector_quantization_amd", "lib", "libvqhip.so"), "rb").read()).hexdigest()[:16]
+
+# ---- bench line + kernel trace of the bench command --------------------------------------------------
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(out, f"{tag}_bench.json"))
+bench = json.load(open(os.path.join(src, "bench.json")))
+assert bench["library_sha256_16"] == lib_sha, "bench.json was made with another library build"
 stats = glob.glob(os.path.join(src, "prof", "**", "bench_kernel_stats.csv"), recursive=True)[0]
-shutil.copy(stats, os.path.join(out, f"{tag}_bench_kernel_stats.csv"))
-trace = glob.glob(os.path.join(src, "prof", "**", "bench_kernel_trace.csv"), recursive=True)[0]
-rows = list(csv.DictReader(open(trace)))
-keep = [r for r in rows if short(r["Kernel_Name"]).startswith("k_")]
-with open(os.path.join(out, f"{tag}_bench_kernel_trace_vq.csv"), "w", newline="") as f:
+rows = [r for r in csv.DictReader(open(stats)) if is_ours(r["Name"])]
+with open(os.path.join(out, f"{tag}_bench_kernel_stats.csv"), "w", newline="") as f:
     w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
     w.writeheader()
-    w.writerows(keep)
+    w.writerows(rows)
+trace = glob.glob(os.path.join(src, "prof", "**", "bench_kernel_trace.csv"), recursive=True)[0]
 dur = collections.defaultdict(list)
-for r in keep:
-    dur[(short(r["Kernel_Name"]), int(r["Grid_Size_X"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-durations = {f"{k}[grid={g}]": dict(n=len(v), median_us=statistics.median(v), mean_us=sum(v) / len(v))
+regs = {}
+for r in csv.DictReader(open(trace)):
+    if not is_ours(r["Kernel_Name"]):
+        continue
+    key = (short(r["Kernel_Name"]), int(r["Grid_Size_X"]))
+    dur[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    regs[key] = dict(vgpr=int(r["VGPR_Count"]), sgpr=int(r["SGPR_Count"]), lds=int(r["LDS_Block_Size"]),
+                     scratch=int(r["Scratch_Size"]), workgroup=int(r["Workgroup_Size_X"]))
+durations = {f"{k}[grid={g}]": dict(n=len(v), median_us=statistics.median(v), mean_us=sum(v) / len(v), min_us=min(v), **regs[(k, g)])
              for (k, g), v in sorted(dur.items())}
+json.dump(durations, open(os.path.join(out, f"{tag}_bench_kernel_durations.json"), "w"), indent=1)
 
-# ---- PMC passes ------------------------------------------------------------------------------------------
+# ---- PMC passes over tools/prof_encode.py ------------------------------------------------------------------
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for name in ("sq1", "sq2", "fetch", "write"):
     files = glob.glob(os.path.join(src, "pmc", name, "**", "p_counter_collection.csv"), recursive=True)
     if not files:
         continue
-    rows = list(csv.DictReader(open(files[0])))
-    keep = [r for r in rows if short(r["Kernel_Name"]).startswith("k_")]
+    rows = [r for r in csv.DictReader(open(files[0])) if is_ours(r["Kernel_Name"])]
     with open(os.path.join(out, f"{tag}_pmc_{name}.csv"), "w", newline="") as f:
         w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
         w.writeheader()
-        w.writerows(keep)
-    for r in keep:
+        w.writerows(rows)
+    for r in rows:
         key = f"{short(r['Kernel_Name'])}[grid={r.get('Grid_Size', r.get('Grid_Size_X', ''))}]"
         agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 per_kernel = []
@@ -59,43 +72,26 @@ for key in sorted(agg):
     c = {n: sum(v) / len(v) for n, v in agg[key].items()}
     e = dict(kernel=key, dispatches=max(len(v) for v in agg[key].values()), counters=c)
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-        # FETCH_SIZE / WRITE_SIZE count KB; FETCH_SIZE is doubled (gfx950 correction for wide reads)
+        # FETCH_SIZE / WRITE_SIZE count KB; FETCH_SIZE is doubled (gfx950 correction for wide coalesced reads)
         e["hbm_read_bytes"] = c["FETCH_SIZE"] * 1024 * 2
         e["hbm_write_bytes"] = c["WRITE_SIZE"] * 1024
     if "GRBM_GUI_ACTIVE" in c and "SQ_INSTS_VALU" in c:
         e["shader_cycles"] = c["GRBM_GUI_ACTIVE"] / 8              # the counter adds the 8 XCDs
-        e["valu_busy_frac"] = c["SQ_INSTS_VALU"] * 4 / (e["shader_cycles"] * 1024)   # 4 cycles per wave64 op, 1024 SIMDs
+        e["valu_issue_busy_frac"] = c["SQ_INSTS_VALU"] * 4 / (e["shader_cycles"] * 1024)   # 4 cycles per wave64 op, 1024 SIMDs
     per_kernel.append(e)
 json.dump(per_kernel, open(os.path.join(out, f"{tag}_pmc_per_kernel.json"), "w"), indent=1)
 
-
-def find(prefix, grid):
-    for e in per_kernel:
-        if e["kernel"].startswith(prefix) and e["kernel"].endswith(f"[grid={grid}]"):
-            return e
-    return None
-
-
 N = 2048 * 2048
-sort_k = find("k_window_sort<true>", 524288)
-prune_k = find("k_assign_fast<8, 4, 0, false, true>", 1048576)
-full_k = find("k_assign_fast<8, 4, 0, false, false>", 1048576)
-fix_k = find("k_fixup<true>", 262144)
+big = [e for e in per_kernel if "hbm_read_bytes" in e]
 summary = dict(
-    workload="encode only, 8192x8192 gray, 4x4 blocks, K=256 (N = 4194304 block vectors)",
-    kernels=["k_window_sort<true>", "k_assign_fast<8,4,packed,pruned>", "k_fixup<true>"],
-    hbm_bytes_per_launch=sum(e["hbm_read_bytes"] + e["hbm_write_bytes"] for e in (sort_k, prune_k, fix_k) if e),
-    hbm_bytes_by_kernel={e["kernel"]: e["hbm_read_bytes"] + e["hbm_write_bytes"] for e in (sort_k, prune_k, fix_k) if e},
-    algorithmic_bytes_per_launch=N * 20,
-    pruned_search=dict(valu_wave_insts=prune_k["counters"]["SQ_INSTS_VALU"],
-                       valu_busy_frac_under_pmc=prune_k["valu_busy_frac"],
-                       share_of_full_search_valu=prune_k["counters"]["SQ_INSTS_VALU"] / full_k["counters"]["SQ_INSTS_VALU"]),
-    full_search=dict(valu_wave_insts=full_k["counters"]["SQ_INSTS_VALU"], valu_busy_frac=full_k["valu_busy_frac"],
-                     hbm_bytes_per_launch=full_k["hbm_read_bytes"] + full_k["hbm_write_bytes"]),
-    kernel_durations_us=durations,
-    note="FETCH_SIZE (KB) doubled per the gfx950 correction for wide coalesced reads; WRITE_SIZE (KB) as is; "
-         "separate rocprofv3 --pmc passes over tools/prof_encode.py.  The PMC passes ran on the build before the "
-         "ambiguous-vector queue was split into 64 sub-queues (that change removed a stall, not instructions or "
-         "bytes); kernel_durations_us come from the kernel trace of the bench run on the final build.")
-json.dump(summary, open(os.path.join(out, f"{tag}_pmc_encode_summary.json"), "w"), indent=1)
-print(json.dumps({k: v for k, v in summary.items() if k != "kernel_durations_us"}, indent=1))
+    library_sha256_16=lib_sha,
+    workload="tools/prof_encode.py: 8192x8192 gray, 4x4 blocks, K=256 (N = 4194304 block vectors)",
+    hbm_bytes_by_kernel={e["kernel"]: e["hbm_read_bytes"] + e["hbm_write_bytes"] for e in big
+                         if e["kernel"].endswith("[grid=1048576]") or e["kernel"].startswith(("k_window_sort", "k_decode", "k_blocks"))},
+    valu={e["kernel"]: dict(valu_wave_insts=e["counters"]["SQ_INSTS_VALU"], valu_issue_busy_frac=e["valu_issue_busy_frac"])
+          for e in per_kernel if "valu_issue_busy_frac" in e and e["kernel"].startswith("k_assign_fast") and e["kernel"].endswith("[grid=1048576]")},
+    note="FETCH_SIZE (KB) doubled per the gfx950 correction for wide coalesced reads; WRITE_SIZE (KB) as is; separate "
+         "rocprofv3 --pmc passes over tools/prof_encode.py on the library build named above (PMC passes run at lower "
+         "clocks than un-profiled runs: durations come from the kernel trace, not from these passes).")
+json.dump(summary, open(os.path.join(out, f"{tag}_pmc_summary.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1))

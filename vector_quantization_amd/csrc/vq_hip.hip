@@ -514,8 +514,34 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long h, unsign
     return h;
 }
 
+// One codebook entry of the fixed-point conversion: rounds cv * scale into the 16-bit half hh of `pair`, adds
+// the rounding error to err, the fixed-point value to sc and the entry's bits to the row hash.
+__device__ __forceinline__ void prep_quant(double cv, int hh, double scale, double qmax, uint32_t &pair, double &err,
+                                           uint32_t &sc, unsigned long long &h) {
+    double t = cv * scale;
+    double q = rint(t);
+    if (!(q >= 0.0)) q = 0.0;          // also catches NaN
+    if (q > qmax) q = qmax;
+    double de = fabs(t - q);
+    if (!(de == de)) de = 4.0e9;
+    err += de;
+    pair |= ((uint32_t)q) << (16 * hh);
+    sc += (uint32_t)q;
+    h = mix64(h, (unsigned long long)__double_as_longlong(cv));
+}
+
+__device__ __forceinline__ uint32_t prep_ceil_sat(double c) {       // ceil, saturated; non-finite counts as huge
+    if (!(c == c) || c > 1.0e9 || c < -1.0e9) return 0x7fffffffu;
+    if (c <= 0.0) return 0u;
+    return (uint32_t)ceil(c);
+}
+
 // Dynamic LDS: an open-addressing table of 2*K slots (keys = 64-bit row hashes), the K row hashes,
 // then per slot the smallest row index seen for its key.
+// SMALL (d <= 16 and K <= 1024, the shapes of the LBG stages of small blocks): one codeword per thread, held
+// in registers from the single read of the codebook to the writes at its sorted place -- one memory round
+// trip instead of five.
+template <bool SMALL>
 __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb, int K, int d, int dp2, uint32_t clim,
                                                   PrepHeader *__restrict__ hdr, uint32_t *__restrict__ c16,
                                                   uint32_t *__restrict__ bias, double *__restrict__ cbT,
@@ -523,7 +549,7 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
     extern __shared__ __align__(16) unsigned long long s_keys[];
     __shared__ uint32_t s_cmax;
     __shared__ uint32_t s_emax;
-    __shared__ uint32_t s_sc[PREP_SORT_CAP];        // element sum of each fixed-point row, original order
+    __shared__ __align__(16) uint32_t s_sc[PREP_SORT_CAP + 4];   // element sum of each fixed-point row, original order
     // the same sums in ascending order: written after the duplicate scan is over, into the space of its hash
     // table (K <= PREP_SORT_CAP codebooks get at least K * 4 bytes of dynamic LDS)
     uint32_t *s_scs = reinterpret_cast<uint32_t *>(s_keys);
@@ -533,25 +559,36 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
     const uint32_t T = scan_dups ? 2u * (uint32_t)K : 0u;       // table slots
     unsigned long long *s_rowhash = s_keys + T;                  // K entries
     uint32_t *s_first = reinterpret_cast<uint32_t *>(s_rowhash + (scan_dups ? K : 0));
+    double creg[SMALL ? 16 : 1];                                 // SMALL: this thread's codeword
+    uint32_t preg[SMALL ? 8 : 1];                                //        and its fixed-point row
     if (threadIdx.x == 0) {
         s_cmax = 0;
         s_emax = 0;
     }
+    if (threadIdx.x < 4 && do_sort) s_sc[K + threadIdx.x] = 0xffffffffu;
     for (uint32_t i = threadIdx.x; i < T; i += blockDim.x) {
         s_keys[i] = 0ull;
         s_first[i] = 0xffffffffu;
     }
     __syncthreads();
-    // phase A: largest entry (ceil, saturated; non-finite counts as huge)
+    // phase A: largest entry
     const int64_t n = (int64_t)K * d;
     uint32_t lmax = 0;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-        double c = cb[i];
-        uint32_t m;
-        if (!(c == c) || c > 1.0e9 || c < -1.0e9) m = 0x7fffffffu;
-        else if (c <= 0.0) m = 0;
-        else m = (uint32_t)ceil(c);
-        lmax = m > lmax ? m : lmax;
+    if constexpr (SMALL) {
+        const int kc = (int)threadIdx.x < K ? (int)threadIdx.x : K - 1;
+        const double *row = cb + (size_t)kc * d;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) creg[e] = row[e < d ? e : d - 1];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const uint32_t m = prep_ceil_sat(creg[e]);
+            lmax = m > lmax ? m : lmax;
+        }
+    } else {
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const uint32_t m = prep_ceil_sat(cb[i]);
+            lmax = m > lmax ? m : lmax;
+        }
     }
     atomicMax(&s_cmax, lmax);
     __syncthreads();
@@ -570,37 +607,38 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
         double err = 0.0;
         uint32_t sc = 0;
         unsigned long long h = 0x243F6A8885A308D3ull;
-        for (int p0 = 0; p0 < dp2; p0 += 4) {
-            double c[8];
+        if constexpr (SMALL) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int e = 2 * p0 + j;
-                c[j] = row[e < d ? e : d - 1];
+            for (int p = 0; p < 8; ++p) {
+                uint32_t pair = 0;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+                    if (2 * p + hh < d) prep_quant(creg[2 * p + hh], hh, scale, qmax, pair, err, sc, h);
+                preg[p] = pair;
             }
+        } else {
+            for (int p0 = 0; p0 < dp2; p0 += 4) {
+                double c[8];
 #pragma unroll
-            for (int pp = 0; pp < 4; ++pp) {
-                const int p = p0 + pp;
-                if (p < dp2) {
-                    uint32_t pair = 0;
+                for (int j = 0; j < 8; ++j) {
+                    const int e = 2 * p0 + j;
+                    c[j] = row[e < d ? e : d - 1];
+                }
 #pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        const int e = 2 * p + hh;
-                        if (e < d) {
-                            const double cv = c[2 * pp + hh];
-                            double t = cv * scale;
-                            double q = rint(t);
-                            if (!(q >= 0.0)) q = 0.0;          // also catches NaN
-                            if (q > qmax) q = qmax;
-                            double de = fabs(t - q);
-                            if (!(de == de)) de = 4.0e9;
-                            err += de;
-                            pair |= ((uint32_t)q) << (16 * hh);
-                            sc += (uint32_t)q;
-                            if (!do_sort) cbT[(size_t)e * K + k] = cv;   // sorted codebooks: written in phase D
-                            h = mix64(h, (unsigned long long)__double_as_longlong(cv));
+                for (int pp = 0; pp < 4; ++pp) {
+                    const int p = p0 + pp;
+                    if (p < dp2) {
+                        uint32_t pair = 0;
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) {
+                            const int e = 2 * p + hh;
+                            if (e < d) {
+                                prep_quant(c[2 * pp + hh], hh, scale, qmax, pair, err, sc, h);
+                                if (!do_sort) cbT[(size_t)e * K + k] = c[2 * pp + hh];   // sorted codebooks: written in phase D
+                            }
                         }
+                        crow_out[(size_t)k * dp2 + p] = pair;
                     }
-                    crow_out[(size_t)k * dp2 + p] = pair;
                 }
             }
         }
@@ -663,14 +701,30 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
             if (do_sort) {
                 const uint32_t me = s_sc[k];
                 pos = 0;
-                for (int j = 0; j < K; ++j) {
-                    const uint32_t o = s_sc[j];
-                    pos += (o < me || (o == me && j < k)) ? 1u : 0u;
+                // four sums per LDS read (entries K .. K + 3 hold 0xffffffff, which never counts)
+                const uint4 *sv = reinterpret_cast<const uint4 *>(s_sc);
+#pragma unroll 4
+                for (int j4 = 0; j4 < (K + 3) / 4; ++j4) {
+                    const uint4 o = sv[j4];
+                    const int j = 4 * j4;
+                    pos += (o.x < me || (o.x == me && j < k)) ? 1u : 0u;
+                    pos += (o.y < me || (o.y == me && j + 1 < k)) ? 1u : 0u;
+                    pos += (o.z < me || (o.z == me && j + 2 < k)) ? 1u : 0u;
+                    pos += (o.w < me || (o.w == me && j + 3 < k)) ? 1u : 0u;
                 }
                 s_scs[pos] = me;
-                for (int p = 0; p < dp2; ++p) c16[(size_t)pos * dp2 + p] = c16u[(size_t)k * dp2 + p];
-                // the transposed fp64 copy follows the sorted order too: cbT[e][pos]
-                for (int e = 0; e < d; ++e) cbT[(size_t)e * K + pos] = cb[(size_t)k * d + e];
+                // the fixed-point row and the transposed fp64 copy go to their sorted place: c16[pos], cbT[e][pos]
+                if constexpr (SMALL) {
+#pragma unroll
+                    for (int p = 0; p < 8; ++p)
+                        if (p < dp2) c16[(size_t)pos * dp2 + p] = preg[p];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (e < d) cbT[(size_t)e * K + pos] = creg[e];
+                } else {
+                    for (int p = 0; p < dp2; ++p) c16[(size_t)pos * dp2 + p] = c16u[(size_t)k * dp2 + p];
+                    for (int e = 0; e < d; ++e) cbT[(size_t)e * K + pos] = cb[(size_t)k * d + e];
+                }
             }
             bias[pos] = (uint32_t)k | (dup << 31);
         }
@@ -2381,10 +2435,12 @@ int run_prepare(const double *cb, int K, int d, void *ws, hipStream_t st) {
     // 2K keys + K hashes + 2K indices; afterwards the first K * 4 bytes hold the sorted element sums
     const size_t hash_lds = (K <= PREP_HASH_CAP && K > 1) ? (size_t)K * 32 : 16;
     static_assert(PREP_SORT_CAP <= PREP_HASH_CAP, "sorted codebooks have a hash table to put their sums in");
+    const bool small = d <= 16 && K <= 1024;                // one codeword per thread, kept in registers
+    auto kern = small ? k_prepare<true> : k_prepare<false>;
     if (hash_lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_prepare), hipFuncAttributeMaxDynamicSharedMemorySize,
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)hash_lds));
-    hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1024), hash_lds, st, cb, K, d, dp2, key_layout(K, dp2).clim,
+    hipLaunchKernelGGL(kern, dim3(1), dim3(1024), hash_lds, st, cb, K, d, dp2, key_layout(K, dp2).clim,
                        reinterpret_cast<PrepHeader *>(w + L.header),
                        reinterpret_cast<uint32_t *>(w + L.c16), reinterpret_cast<uint32_t *>(w + L.bias),
                        reinterpret_cast<double *>(w + L.cbT), reinterpret_cast<uint32_t *>(w + L.c16u),
