@@ -62,7 +62,7 @@ def test_emu_window_sort(eng, N, d):
     _check_sorted(eng.sort_blocks(T(blocks)), blocks)
 
 
-@pytest.mark.parametrize("N,d", [(700, 16), (8192 + 300, 16), (3000, 4), (2600, 12), (1900, 8)])
+@pytest.mark.parametrize("N,d", [(700, 16), (8192 + 300, 16), (3000, 4), (2600, 12), (1900, 8), (6 * 8192 - 100, 8)])
 def test_emu_window_sort_lds_variant(eng, N, d):
     """Rows of 1 .. 4 aligned words take the LDS-staged sort kernel: it produces a valid sorted copy."""
     rng = np.random.default_rng(N * 3 + d)

@@ -767,6 +767,8 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
 struct SrcBlocks {
     const uint8_t *p;
     int d;
+    __device__ __forceinline__ bool quads() const { return false; }
+    __device__ __forceinline__ void quad_words(int64_t, uint32_t (&)[4][4]) const {}
     __device__ __forceinline__ uint32_t byte(int64_t n, int e) const { return p[(size_t)n * d + e]; }
     // word w of vector n (rows are whole aligned words)
     __device__ __forceinline__ uint32_t word(int64_t n, int w) const {
@@ -797,6 +799,19 @@ struct SrcImage {
     int H, W, C, bh, bw, pad_zero;
     uint32_t nc, seg, d;          // blocks per block row, bytes per block row segment (bw * C), bh * seg
     int words_ok;                 // image rows are whole aligned words (W * C % 4 == 0, base aligned)
+    int quads_ok;                 // 4x4 blocks of 1-byte pixels, no padding, image rows multiples of 16 aligned bytes
+    __device__ __forceinline__ bool quads() const { return quads_ok != 0; }
+    // quads_ok: the four consecutive vectors n0 .. n0 + 3 (n0 a multiple of 4: four horizontally adjacent blocks)
+    // from four 16-byte loads, one per pixel row; w[m] = the four row words of vector n0 + m
+    __device__ __forceinline__ void quad_words(int64_t n0, uint32_t (&w)[4][4]) const {
+        const uint32_t r = (uint32_t)n0 / nc, q = (uint32_t)n0 - r * nc;
+        const uint8_t *base = img + ((size_t)r * 4) * (size_t)W + (size_t)q * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(base + (size_t)i * W);
+            w[0][i] = v.x; w[1][i] = v.y; w[2][i] = v.z; w[3][i] = v.w;
+        }
+    }
     __device__ __forceinline__ uint32_t byte_at(uint32_t r, uint32_t q, uint32_t e) const {
         const uint32_t i = e / seg, rem = e - i * seg;
         const uint32_t j = rem / (uint32_t)C, ch = rem - j * (uint32_t)C;
@@ -949,66 +964,111 @@ __global__ __launch_bounds__(1024) void k_window_sort_lds(const SRC src, int64_t
     __shared__ uint32_t s_cnt[SORT_BUCKETS];
     __shared__ uint32_t s_wsum[T / WAVE];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
-    const int64_t w0 = (int64_t)blockIdx.x * SORT_WIN;
-    const int count = (int)((N - w0) < SORT_WIN ? (N - w0) : SORT_WIN);      // vectors in this window
-    for (int i = tid; i < SORT_BUCKETS; i += T) s_cnt[i] = 0u;
-    __syncthreads();
-    uint32_t keep[PER][DW];
-    uint32_t bucket[PER], rank[PER];
+    const int64_t nwin = (N + SORT_WIN - 1) / SORT_WIN;
+    // A workgroup walks windows blockIdx.x, + gridDim.x, ...: the rows of its NEXT window are requested before
+    // the current one is written out, so that the loads of one window travel while the stores of the other do.
+    uint32_t keep[PER][DW], nxt[PER][DW];
+    // position inside the window of this thread's j-th vector: strided by the workgroup, or -- when the source
+    // delivers four adjacent blocks from four 16-byte loads -- runs of four consecutive vectors
+    const bool quads = DW == 4 && src.quads();
+    auto li_of = [&](int j) { return quads ? ((j >> 2) * T + tid) * 4 + (j & 3) : j * T + tid; };
+    auto load_window = [&](int64_t win, uint32_t (&dst)[PER][DW]) {
+        const int64_t w0 = win * SORT_WIN;
+        const int count = (int)((N - w0) < SORT_WIN ? (N - w0) : SORT_WIN);
+        if constexpr (DW == 4) {
+            if (quads) {                                    // (uniform) N is a multiple of 4 here
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const int li = j * T + tid;
-        const int lc = li < count ? li : count - 1;         // clamped: loads stay in bounds
-        src.template row_words<DW>(w0 + lc, keep[j]);
-    }
+                for (int g = 0; g < PER / 4; ++g) {
+                    const int li = (g * T + tid) * 4;
+                    const int lc = li < count ? li : count - 4;
+                    uint32_t w[4][4];
+                    src.quad_words(w0 + lc, w);
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const int li = j * T + tid;
-        uint32_t sum = 0;
+                    for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int w = 0; w < DW; ++w) sum = __builtin_amdgcn_sad_u8(keep[j][w], 0u, sum);
-        bucket[j] = sum >> bshift;
-        rank[j] = li < count ? atomicAdd(&s_cnt[bucket[j]], 1u) : 0u;
-    }
-    __syncthreads();
-    // exclusive scan of the bucket counts: two buckets per thread, wave scan, then the wave totals
-    const uint32_t c0 = s_cnt[2 * tid], c1 = s_cnt[2 * tid + 1];
-    uint32_t incl = c0 + c1;
-#pragma unroll
-    for (int off = 1; off < WAVE; off <<= 1) {
-        const uint32_t o = __shfl_up(incl, off, WAVE);
-        if (lane >= off) incl += o;
-    }
-    if (lane == WAVE - 1) s_wsum[wv] = incl;
-    __syncthreads();
-    uint32_t wbase = 0;
-    for (int i = 0; i < wv; ++i) wbase += s_wsum[i];
-    const uint32_t excl = wbase + incl - (c0 + c1);
-    __syncthreads();
-    s_cnt[2 * tid] = excl;
-    s_cnt[2 * tid + 1] = excl + c0;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const int li = j * T + tid;
-        if (li < count) {
-            const uint32_t slot = s_cnt[bucket[j]] + rank[j];            // < count
-#pragma unroll
-            for (int w = 0; w < DW; ++w) s_rows[(size_t)slot * DW + w] = keep[j][w];
-            s_perm[slot] = (uint16_t)li;
+                        for (int i = 0; i < 4; ++i) dst[g * 4 + m][i] = w[m][i];
+                }
+                return;
+            }
         }
-    }
-    __syncthreads();
-    // write the window out in order
-    uint32_t *orow = rows + (size_t)w0 * DW;
-    for (int i = tid; i < count * DW; i += T) orow[i] = s_rows[i];
-    uint16_t *operm = perm + w0;
-    if ((count & 1) == 0 && (reinterpret_cast<uintptr_t>(operm) & 3) == 0) {
-        const uint32_t *sp = reinterpret_cast<const uint32_t *>(s_perm);
-        uint32_t *op = reinterpret_cast<uint32_t *>(operm);
-        for (int i = tid; i < count / 2; i += T) op[i] = sp[i];
-    } else {
-        for (int i = tid; i < count; i += T) operm[i] = s_perm[i];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int li = j * T + tid;
+            const int lc = li < count ? li : count - 1;     // clamped: loads stay in bounds
+            src.template row_words<DW>(w0 + lc, dst[j]);
+        }
+    };
+    if ((int64_t)blockIdx.x < nwin) load_window(blockIdx.x, keep);
+    for (int64_t win = blockIdx.x; win < nwin; win += gridDim.x) {
+        const int64_t w0 = win * SORT_WIN;
+        const int count = (int)((N - w0) < SORT_WIN ? (N - w0) : SORT_WIN);  // vectors in this window
+        for (int i = tid; i < SORT_BUCKETS; i += T) s_cnt[i] = 0u;
+        __syncthreads();
+        uint32_t bucket[PER], rank[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int li = li_of(j);
+            uint32_t sum = 0;
+#pragma unroll
+            for (int w = 0; w < DW; ++w) sum = __builtin_amdgcn_sad_u8(keep[j][w], 0u, sum);
+            bucket[j] = sum >> bshift;
+            rank[j] = li < count ? atomicAdd(&s_cnt[bucket[j]], 1u) : 0u;
+        }
+        __syncthreads();
+        // exclusive scan of the bucket counts: two buckets per thread, wave scan, then the wave totals
+        const uint32_t c0 = s_cnt[2 * tid], c1 = s_cnt[2 * tid + 1];
+        uint32_t incl = c0 + c1;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, WAVE);
+            if (lane >= off) incl += o;
+        }
+        if (lane == WAVE - 1) s_wsum[wv] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (int i = 0; i < wv; ++i) wbase += s_wsum[i];
+        const uint32_t excl = wbase + incl - (c0 + c1);
+        __syncthreads();
+        s_cnt[2 * tid] = excl;
+        s_cnt[2 * tid + 1] = excl + c0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int li = li_of(j);
+            if (li < count) {
+                const uint32_t slot = s_cnt[bucket[j]] + rank[j];            // < count
+#pragma unroll
+                for (int w = 0; w < DW; ++w) s_rows[(size_t)slot * DW + w] = keep[j][w];
+                s_perm[slot] = (uint16_t)li;
+            }
+        }
+        // the next window's rows start travelling now
+        const int64_t next = win + gridDim.x;
+        if (next < nwin) load_window(next, nxt);
+        __syncthreads();
+        // write the window out in order, 16 bytes per lane where the window allows it
+        uint32_t *orow = rows + (size_t)w0 * DW;
+        const int words = count * DW;
+        if ((words & 3) == 0) {
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(s_rows);
+            uint4 *o4 = reinterpret_cast<uint4 *>(orow);           // rows is 16-byte aligned, w0 * DW * 4 a multiple of 16
+            for (int i = tid; i < words / 4; i += T) o4[i] = s4[i];
+        } else {
+            for (int i = tid; i < words; i += T) orow[i] = s_rows[i];
+        }
+        uint16_t *operm = perm + w0;
+        if ((count & 7) == 0 && (reinterpret_cast<uintptr_t>(operm) & 15) == 0) {
+            const uint4 *sp = reinterpret_cast<const uint4 *>(s_perm);
+            uint4 *op = reinterpret_cast<uint4 *>(operm);
+            for (int i = tid; i < count / 8; i += T) op[i] = sp[i];
+        } else {
+            for (int i = tid; i < count; i += T) operm[i] = s_perm[i];
+        }
+        __syncthreads();                                    // the LDS image is free for the next window
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+#pragma unroll
+            for (int w = 0; w < DW; ++w) keep[j][w] = nxt[j][w];
     }
 }
 
@@ -2745,7 +2805,7 @@ int run_sort(const SRC &src, bool row_words_ok, int64_t N, int d, void *sorted, 
         if (lds > 48 * 1024)                                                                                        \
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                       \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, st, src, N, bshift, r32, perm, shdr);                 \
+        hipLaunchKernelGGL(kern, dim3(grid < di.cus ? grid : di.cus), dim3(1024), lds, st, src, N, bshift, r32, perm, shdr); \
     } while (0)
         switch (d / 4) {
             case 1: VQ_LAUNCH_SORT(1); break;
@@ -2920,6 +2980,7 @@ int vq_blocks_sort_img(const uint8_t *img, int H, int W, int C, int bh, int bw, 
     src.img = img; src.H = H; src.W = W; src.C = C; src.bh = bh; src.bw = bw; src.pad_zero = pad_mode == VQ_PAD_ZERO;
     src.nc = (uint32_t)nc; src.seg = (uint32_t)(bw * C); src.d = (uint32_t)d;
     src.words_ok = (((int64_t)W * C) % 4 == 0) && ((reinterpret_cast<uintptr_t>(img) & 3) == 0);
+    src.quads_ok = C == 1 && bh == 4 && bw == 4 && H % 4 == 0 && W % 16 == 0 && (reinterpret_cast<uintptr_t>(img) & 15) == 0;
     return run_sort(src, d % 4 == 0, nr * nc, d, sorted, sorted_bytes, static_cast<hipStream_t>(stream));
 }
 
