@@ -32,7 +32,8 @@ def _structured(rng, K, d, N, noise=10.0):
     return blocks, cb
 
 
-@pytest.mark.parametrize("shape,bh,bw,pad", [((33, 17, 1), 4, 4, 0), ((7, 5, 3), 2, 2, 1), ((64, 64, 1), 4, 4, 0)])
+@pytest.mark.parametrize("shape,bh,bw,pad", [((33, 17, 1), 4, 4, 0), ((7, 5, 3), 2, 2, 1), ((64, 64, 1), 4, 4, 0),
+                                             ((52, 1040, 1), 4, 4, 0), ((1028, 528, 1), 4, 4, 1)])
 def test_emu_blocks(eng, oracle, shape, bh, bw, pad):
     img = np.random.default_rng(1).integers(0, 256, size=shape, dtype=np.uint8)
     got = eng.blocks_from_image(T(img), bh, bw, pad).numpy()
@@ -162,9 +163,12 @@ def test_emu_codebook_class_reproduces_reference_golden(tmp_path):
         assert np.array_equal(arr, g["decoded"])
 
 
-@pytest.mark.parametrize("K,bh,bw,C,nr,nc", [(256, 4, 4, 1, 16, 64), (17, 2, 2, 3, 5, 8), (33, 8, 8, 3, 3, 4), (9, 3, 3, 1, 4, 5)])
+@pytest.mark.parametrize("K,bh,bw,C,nr,nc", [(256, 4, 4, 1, 16, 64), (17, 2, 2, 3, 5, 8), (33, 8, 8, 3, 3, 4), (9, 3, 3, 1, 4, 5),
+                                             (4100, 4, 4, 1, 9, 300), (31, 4, 4, 1, 40, 1800), (12, 4, 2, 2, 7, 44),
+                                             (50, 4, 4, 1, 6, 30)])
 def test_emu_decode_both_kernels(eng, oracle, K, bh, bw, C, nr, nc):
-    """Word-wide block rows take k_decode_blockrows_u8, the rest the byte-wise k_decode_u8."""
+    """16-byte codewords of four 4-byte pixel rows take k_decode_quads (codebook in LDS or not, several trips),
+    other word-wide block rows k_decode_blockrows_u8, the rest the byte-wise k_decode_u8."""
     rng = np.random.default_rng(K + nr)
     cb = rng.random((K, bh * bw * C)) * 300.0 - 20.0
     labels = rng.integers(0, K, size=(nr, nc)).astype(np.int32)

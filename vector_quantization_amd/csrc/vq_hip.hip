@@ -399,6 +399,38 @@ __global__ __launch_bounds__(256) void k_blocks_u8(const uint8_t *__restrict__ i
     }
 }
 
+// 4x4 blocks of one-byte pixels, no padding, image rows multiples of 16 aligned bytes: a thread reads four
+// horizontally adjacent blocks with four 16-byte loads (one per pixel row; a wave's loads are contiguous
+// runs of the four rows) and regroups the words into the four 16-byte vectors.  The vectors go through LDS so
+// that every store instruction of a wave writes 1 KB of consecutive vectors.
+__global__ __launch_bounds__(256) void k_blocks_quads(const uint8_t *__restrict__ img, int W, uint8_t *__restrict__ blocks,
+                                                      int nc, int64_t total_quads) {
+    __shared__ uint4 s_vec[1024];
+    const int tid = threadIdx.x;
+    for (int64_t q0 = (int64_t)blockIdx.x * 256; q0 < total_quads; q0 += (int64_t)gridDim.x * 256) {   // (uniform)
+        const int64_t qg = q0 + tid;
+        if (qg < total_quads) {
+            const uint32_t n0 = (uint32_t)qg * 4, r = n0 / (uint32_t)nc, q = n0 - r * (uint32_t)nc;
+            const uint8_t *base = img + ((size_t)r * 4) * (size_t)W + (size_t)q * 4;
+            uint4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const uint4 *>(base + (size_t)i * W);
+            s_vec[tid * 4 + 0] = make_uint4(v[0].x, v[1].x, v[2].x, v[3].x);
+            s_vec[tid * 4 + 1] = make_uint4(v[0].y, v[1].y, v[2].y, v[3].y);
+            s_vec[tid * 4 + 2] = make_uint4(v[0].z, v[1].z, v[2].z, v[3].z);
+            s_vec[tid * 4 + 3] = make_uint4(v[0].w, v[1].w, v[2].w, v[3].w);
+        }
+        __syncthreads();
+        const int64_t rem = (total_quads - q0) * 4;
+        const int count = (int)(rem < 1024 ? rem : 1024);
+        uint4 *out = reinterpret_cast<uint4 *>(blocks) + q0 * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k * 256 + tid < count) out[k * 256 + tid] = s_vec[k * 256 + tid];
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // column sums (initial centroid, VQ_Full.py:67)
 // ------------------------------------------------------------------------------------------------
@@ -2276,6 +2308,54 @@ __global__ __launch_bounds__(256) void k_decode_blockrows_u8(const int32_t *__re
     }
 }
 
+// Decode of 16-byte codewords that are 4 pixel rows of 4 bytes (4x4 blocks of one-byte pixels, 2x2 of two-byte
+// ones ...): a thread takes four horizontally adjacent blocks -- one 16-byte load of their labels, one 16-byte
+// read of each codeword from the truncated codebook (LDS when it fits) -- and writes the four pixel rows with
+// one 16-byte store each, so a wave's stores are 1 KB runs of an image row.  Two items per thread and trip,
+// label loads first.
+template <bool LDS_CB>
+__global__ __launch_bounds__(1024) void k_decode_quads(const int32_t *__restrict__ labels, int nr, int nc,
+                                                       const double *__restrict__ cb, const uint8_t *__restrict__ cb8g,
+                                                       int K, uint8_t *__restrict__ img) {
+    extern __shared__ __align__(16) uint8_t s_cb8[];
+    const uint32_t qpr = (uint32_t)nc / 4;                       // quads per block row
+    const size_t rowbytes = (size_t)nc * 4;
+    const int64_t total = (int64_t)nr * qpr;
+    const uint4 *lab4 = reinterpret_cast<const uint4 *>(labels);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint4 la = t < total ? lab4[t] : make_uint4(0, 0, 0, 0);
+    uint4 lb = t + stride < total ? lab4[t + stride] : make_uint4(0, 0, 0, 0);
+    if (LDS_CB) {                                                // truncate the fp64 codebook into LDS, a word per trip
+        for (int i = threadIdx.x; i < K * 4; i += blockDim.x) {
+            const double *c = cb + (size_t)i * 4;
+            reinterpret_cast<uint32_t *>(s_cb8)[i] = (uint32_t)cast_u8(c[0]) | (uint32_t)cast_u8(c[1]) << 8 |
+                                                     (uint32_t)cast_u8(c[2]) << 16 | (uint32_t)cast_u8(c[3]) << 24;
+        }
+        __syncthreads();
+    }
+    const uint4 *cw = reinterpret_cast<const uint4 *>(LDS_CB ? s_cb8 : cb8g);
+    auto emit = [&](int64_t item, const uint4 &l) {
+        const uint32_t r = (uint32_t)(item / qpr), qx = (uint32_t)(item - (int64_t)r * qpr);
+        const uint4 c0 = cw[l.x], c1 = cw[l.y], c2 = cw[l.z], c3 = cw[l.w];
+        uint8_t *o = img + (size_t)r * 4 * rowbytes + (size_t)qx * 16;
+        *reinterpret_cast<uint4 *>(o) = make_uint4(c0.x, c1.x, c2.x, c3.x);
+        *reinterpret_cast<uint4 *>(o + rowbytes) = make_uint4(c0.y, c1.y, c2.y, c3.y);
+        *reinterpret_cast<uint4 *>(o + 2 * rowbytes) = make_uint4(c0.z, c1.z, c2.z, c3.z);
+        *reinterpret_cast<uint4 *>(o + 3 * rowbytes) = make_uint4(c0.w, c1.w, c2.w, c3.w);
+    };
+    while (t < total) {
+        const int64_t t2 = t + 2 * stride;
+        const uint4 na = t2 < total ? lab4[t2] : make_uint4(0, 0, 0, 0);
+        const uint4 nb = t2 + stride < total ? lab4[t2 + stride] : make_uint4(0, 0, 0, 0);
+        emit(t, la);
+        if (t + stride < total) emit(t + stride, lb);
+        la = na;
+        lb = nb;
+        t = t2;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // label bit-packing (VQ_Full.py:134-147) and its inverse
 // ------------------------------------------------------------------------------------------------
@@ -2853,7 +2933,11 @@ int vq_blocks_u8(const uint8_t *img, int H, int W, int C, int bh, int bw, int pa
     const int words_ok = (((int64_t)W * C) % 4 == 0) && ((reinterpret_cast<uintptr_t>(img) & 3) == 0);
     const bool seg4 = (bw * C) % 4 == 0;
     const int pz = pad_mode == VQ_PAD_ZERO;
-    if (seg4 && total % 16 == 0 && (optr & 15) == 0) {
+    if (C == 1 && bh == 4 && bw == 4 && H % 4 == 0 && W % 16 == 0 && (optr & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(img) & 15) == 0 && (int64_t)nr * nc < (1ll << 31)) {
+        const int64_t quads = (int64_t)nr * nc / 4;
+        hipLaunchKernelGGL(k_blocks_quads, dim3(grid_for(quads, 256, 16384)), dim3(256), 0, st, img, W, blocks, nc, quads);
+    } else if (seg4 && total % 16 == 0 && (optr & 15) == 0) {
         int64_t groups = total / 16;
         hipLaunchKernelGGL(k_blocks_u8<16>, dim3(grid_for(groups, 256, 16384)), dim3(256), 0, st, img, H, W, C, bh, bw, pz,
                            blocks, nc, groups, words_ok);
@@ -3225,6 +3309,26 @@ int vq_decode_u8(const int32_t *labels, int nr, int nc, const double *cb, int K,
     if (rowbytes > 0x7fffffffLL || (int64_t)nr * bh > 0x7fffffffLL) return fail(VQ_E_UNSUPPORTED, "image too large");
     const bool lds_cb = n <= 64 * 1024;
     const size_t lds = lds_cb ? (size_t)((n + 15) / 16 * 16) : 0;
+    DeviceInfo di;
+    int rc2 = device_info(di);
+    if (rc2) return rc2;
+    if (d == 16 && bh == 4 && nc % 4 == 0 && (reinterpret_cast<uintptr_t>(img) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(labels) & 15) == 0) {
+        const int64_t quads = (int64_t)nr * (nc / 4);
+        const int grid = grid_for((quads + 1) / 2, 1024, di.cus * 2);
+        if (lds_cb) {
+            if (lds > 48 * 1024)
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_decode_quads<true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_decode_quads<true>), dim3(grid), dim3(1024), lds, st, labels, nr, nc, cb, cb8, K, img);
+        } else {
+            hipLaunchKernelGGL(k_cb_to_u8, dim3(grid_for(n, 256, 4096)), dim3(256), 0, st, cb, n, cb8);
+            LAUNCH_CHECK("k_cb_to_u8");
+            hipLaunchKernelGGL((k_decode_quads<false>), dim3(grid), dim3(1024), 0, st, labels, nr, nc, cb, cb8, K, img);
+        }
+        LAUNCH_CHECK("k_decode_quads");
+        return VQ_OK;
+    }
     if (!lds_cb) {
         hipLaunchKernelGGL(k_cb_to_u8, dim3(grid_for(n, 256, 4096)), dim3(256), 0, st, cb, n, cb8);
         LAUNCH_CHECK("k_cb_to_u8");
@@ -3232,9 +3336,6 @@ int vq_decode_u8(const int32_t *labels, int nr, int nc, const double *cb, int K,
     const uintptr_t iptr = reinterpret_cast<uintptr_t>(img);
     const bool seg4 = (bw * C) % 4 == 0;
     const int G = (seg4 && rowbytes % 16 == 0 && (iptr & 15) == 0) ? 16 : ((seg4 && (iptr & 3) == 0) ? 4 : 1);
-    DeviceInfo di;
-    int rc2 = device_info(di);
-    if (rc2) return rc2;
     // a fixed number of workgroups (each stages the codebook once) laid out as (x over a row, y over rows)
     const int64_t groups_per_row = rowbytes / G;
     int gx = grid_for(groups_per_row, 256, 64);
