@@ -95,8 +95,7 @@ int vq_encode_l1_static(const uint8_t *blocks, int64_t N, int d, const double *c
  * Passing it to vq_encode_l1_prepared / vq_lbg_accum lets the search skip every codeword whose
  * element sum differs from the vector's by more than the best distance found (a lower bound of
  * the L1 distance), with identical results.  vq_prune_supported(K, d) tells whether a (K, d)
- * codebook is served by that search (else `sorted` is ignored): 32 <= K <= 2048 with rows of at most
- * 64 bytes and a fixed-point codebook of at most 32 KB.
+ * codebook is served by that search (else `sorted` is ignored): 32 <= K <= 4096 and d <= 192.
  * vq_blocks_sort ends the buffer with a (magic, N, d) header and records on the host which buffer it
  * filled for which (N, d).  A search that is handed a `sorted` argument it has no such record of, one
  * recorded for another N or d, or one smaller than vq_sorted_bytes(d, N), returns VQ_E_INVALID; a
@@ -137,8 +136,10 @@ int vq_encode_l1_prepared(const uint8_t *blocks, const void *sorted, size_t sort
  * vectors the last filter pass queued in this ws, 3 both (= vq_encode_l1_prepared).  After a filter pass
  * the workspace holds two statistics per sub-queue slot q (q = 0 .. 63) at byte offset
  * vq_workspace_counters_offset(K, d, N) + 64 * q: at byte 0 a uint32 count of vectors queued for the
- * fix-up, at byte 8 a uint64 count of the (vector, codeword) pairs whose distance the filter evaluated
- * (N * K rounded up to the kernel's batch without pruning). */
+ * fix-up, at byte 4 a uint32 count of near-ties the filter kernel settled in fp64 itself (the pruned search
+ * with scalar-loaded codewords does that and queues nothing: its phase 2 is empty), at byte 8 a uint64 count
+ * of the (vector, codeword) pairs whose distance the filter evaluated (N * K rounded up to the kernel's batch
+ * without pruning). */
 int vq_encode_l1_prepared_phases(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d,
                                  const double *cb, int K, int32_t *labels, double *min_dist, int phases, void *ws,
                                  size_t ws_bytes, void *stream);

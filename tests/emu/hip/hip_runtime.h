@@ -185,6 +185,7 @@ inline uint32_t emu_perm(uint32_t s0, uint32_t s1, uint32_t sel) {     // v_perm
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline long long __double_as_longlong(double d) { long long r; memcpy(&r, &d, 8); return r; }
+inline double __longlong_as_double(long long v) { double r; memcpy(&r, &v, 8); return r; }
 inline uint32_t min(uint32_t a, uint32_t b) { return a < b ? a : b; }
 inline uint32_t max(uint32_t a, uint32_t b) { return a > b ? a : b; }
 inline int min(int a, int b) { return a < b ? a : b; }

@@ -1116,6 +1116,7 @@ struct AssignArgs {
     int64_t N;
     int d;
     const double *cb;           // (K, d) row-major fp64
+    const double *cbT;          // transposed fp64 copy, columns in the order of the fixed-point rows
     int K;
     int kbits;
     const PrepHeader *hdr;
@@ -1137,6 +1138,9 @@ struct AssignArgs {
     const SortedHeader *shdr;   // what the sorted copy holds (verified before the origin map is trusted)
     Gate gate;
 };
+
+// Whether a filter variant settles near-ties inside the kernel (see RESOLVE in k_assign_fast).
+constexpr bool resolves_in_kernel(int dp2, bool lds_cw, bool prune) { return prune && !lds_cw && dp2 <= 16; }
 
 // Codewords per LDS tile of the LDS_CW variant (about 4 KB of fixed-point rows per tile).
 constexpr int tile_k_for(int dp2) { return dp2 <= 8 ? 128 : (dp2 <= 16 ? 64 : (dp2 <= 32 ? 32 : (dp2 <= 64 ? 16 : 8))); }
@@ -1169,7 +1173,8 @@ constexpr int tile_k_for(int dp2) { return dp2 <= 8 ? 128 : (dp2 <= 16 ? 64 : (d
 // elements per instruction -- so that one atomic instruction spreads over 16+ distinct addresses.
 template <int DP2, int R, int KEYMODE, bool LDS_CW, bool PRUNE, bool ACC = false>
 __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const AssignArgs a, const uint32_t *__restrict__ c16,
-                                                     const uint32_t *__restrict__ bias) {
+                                                     const uint32_t *__restrict__ bias,
+                                                     const double *__restrict__ cbrows) {
     static_assert(!ACC || (PRUNE && DP2 <= 16), "the fused accumulation belongs to the pruned variant");
     // dynamic LDS, LDS_CW: [2 tiles of TILE_K * DP2 words][2 x TILE_K bias words]
     //              ACC:    [(K + 1) rows of 2*DP2 byte sums | count | pad][per wave: 64 rows of EPL bytes, 64 labels]
@@ -1181,6 +1186,10 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
     const int d = a.d, K = a.K;
     const bool want_dist = a.min_dist != nullptr;
     constexpr int EPL = 2 * DP2;                               // staged bytes per row (elements beyond d are zero)
+    // The scalar-load pruned search settles its near-ties itself (no queue, no fix-up launch): the rows a wave
+    // searched contain every codeword that can be nearest to any of its vectors, so the wave evaluates that
+    // range in fp64 for each ambiguous vector in turn.
+    constexpr bool RESOLVE = resolves_in_kernel(DP2, LDS_CW, PRUNE);
     // LDS table of the fused accumulation: K rows of TROW words -- EPL byte sums (those beyond d stay zero), the
     // member count, one pad word, so that element pairs sit on 8-byte boundaries; row K is a dummy (never flushed)
     constexpr int TROW = EPL + 2;
@@ -1274,6 +1283,7 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
         }
         // ---- filter: two smallest keys per vector ----
         uint32_t rows_searched = 0;                            // codebook rows this wave evaluated (wave-uniform)
+        int range_lo = 0, range_hi = 0;                        // RESOLVE: the rows [range_lo, range_hi) it searched
         uint32_t m1[R], m2[R], bi[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -1376,6 +1386,8 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
                     pb = nb;
                 }
                 rows_searched = (uint32_t)(pb - pa);
+                range_lo = pa;
+                range_hi = pb < K ? pb : K;                    // rows K .. Kpad are pad rows
             }
         } else {
             constexpr int TILE_K = tile_k_for(DP2);
@@ -1545,6 +1557,72 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
                 rows_searched = (uint32_t)((tb - ta) * TILE_K);
             }
         }
+        // ---- near-ties settled in the kernel (RESOLVE) ----
+        // the outcome replaces the vector's keys: the winner, and no runner-up
+        if constexpr (RESOLVE) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int64_t ns = vec_index(r);
+                const uint32_t s1 = KEYMODE == KEY_PACKED ? m1[r] >> kbits : m1[r];
+                const uint32_t s2 = KEYMODE == KEY_PACKED ? m2[r] >> kbits : m2[r];
+                const unsigned long long amask = __ballot(ns < a.N && (s2 - s1 <= window));
+                if (amask && lane == 0)                        // statistics: vectors re-checked in fp64
+                    atomicAdd(a.qcount + 16 * ((uint32_t)((ns - lane) >> 6) & (NQ - 1)) + 1, (uint32_t)__popcll(amask));
+                for (unsigned long long todo = amask; todo; todo &= todo - 1ull) {      // (wave-uniform)
+                    const int owner = __ffsll((long long)todo) - 1;
+                    uint32_t xw[DP2];                          // the vector, wave-uniform
+#pragma unroll
+                    for (int p = 0; p < DP2; ++p) xw[p] = __builtin_amdgcn_readlane(x[r][p], owner);
+                    // The nearest codeword in fp64 is among the searched rows whose fixed-point SAD lies within
+                    // the ambiguity window of the smallest one.  Lanes take one row each and recompute its SAD
+                    // (the vector is a scalar operand); for every candidate the wave reads the fp64 codeword
+                    // (one address for all lanes) and sums |x_e - c_e| in element order, the same value in all lanes.
+                    // The lowest codeword index wins ties, as in the fix-up kernels.
+                    const uint32_t s1o = __builtin_amdgcn_readlane(s1, owner);
+                    const uint32_t lim = s1o + window < s1o ? 0xffffffffu : s1o + window;
+                    double best = __builtin_huge_val();
+                    int bk = 0x7fffffff, bpos = 0;
+                    for (int p0 = range_lo; p0 < range_hi; p0 += WAVE) {
+                        const int pos = p0 + lane;
+                        const bool on = pos < range_hi;
+                        const int pc = on ? pos : range_hi - 1;
+                        const uint32_t *crow16 = c16 + (size_t)pc * DP2;
+                        const uint32_t kk_lane = bias[pc] & 0x7fffffffu;
+                        uint32_t sad = 0;
+#pragma unroll
+                        for (int p = 0; p < DP2; ++p) {
+                            sad = __builtin_amdgcn_sad_u16(crow16[p], xw[p], sad);
+                            if (p % 4 == 3) __builtin_amdgcn_sched_barrier(0);     // at most four row words in registers
+                        }
+                        for (unsigned long long cm = __ballot(on && sad <= lim); cm; cm &= cm - 1ull) {
+                            const int cl = __ffsll((long long)cm) - 1;
+                            const int kk = (int)__builtin_amdgcn_readlane(kk_lane, cl);
+                            const double *crow = cbrows + (size_t)kk * d;       // wave-uniform: scalar loads
+                            double acc = 0.0;
+                            uint32_t sv = s;                   // opaque per trip: the element conversions stay inside
+                            asm volatile("" : "+v"(sv));       // the loop (hoisted, they would hold 4 * DP2 registers)
+#pragma unroll
+                            for (int e = 0; e < 2 * DP2; ++e) {
+                                if (e < d) {
+                                    const double xe = (double)((xw[e >> 1] >> (sv + 16 * (e & 1))) & 0xffu);
+                                    acc += fabs(xe - crow[e]);
+                                }
+                            }
+                            if (acc < best || (acc == best && kk < bk)) {
+                                best = acc;
+                                bk = kk;
+                                bpos = p0 + cl;
+                            }
+                        }
+                    }
+                    if (lane == owner) {
+                        if (KEYMODE == KEY_PACKED) m1[r] = (m1[r] & ~kmask) | (uint32_t)bk;
+                        else bi[r] = (uint32_t)bpos;
+                        m2[r] = 0xffffffffu;
+                    }
+                }
+            }
+        }
         // statistics: (vector, codeword) pairs this wave evaluated, summed into the 64-bit word at byte 8 of
         // the wave's sub-queue slot
         if (lane == 0)
@@ -1574,7 +1652,7 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
             }
             // near-tie: the filter cannot rank the two best candidates; queue the vector for the
             // fp64 fix-up kernel (one atomic per wave that has any)
-            const bool amb = valid && (s2 - s1 <= window);
+            const bool amb = !RESOLVE && valid && (s2 - s1 <= window);
             const unsigned long long amask = __ballot(amb);
             if (amask) {
                 const int leader = __ffsll((long long)amask) - 1;
@@ -1798,128 +1876,142 @@ __global__ __launch_bounds__(1024) void k_fixup_pruned(const uint8_t *__restrict
     const double scale = (double)(1u << shift);
     const uint32_t count = qcount[16 * sub];
     queue += (size_t)sub * qcap;
-    // queue entry -> row position, vector index, lane's row byte and the lane's share of the element sum
-    // (three dependent memory round trips); the next item's are requested while the current one is searched
-    auto fetch = [&](uint32_t i, int64_t &nrow, int64_t &nout, uint32_t &xv, uint32_t &part) {
-        nrow = (int64_t)queue[i < count ? i : count - 1];       // wave-uniform
-        nrow = nrow < N ? nrow : N - 1;
-        nout = nrow;                                            // vector index the results are written at
-        if (perm) {                                             // `blocks` is the sorted copy: origin inside the window
-            nout = (nrow & ~(int64_t)(SORT_WIN - 1)) + (int64_t)perm[nrow];
-            nout = nout < N ? nout : N - 1;
-        }
-        const uint8_t *xr = blocks + (size_t)nrow * d;
-        xv = lane < d ? (uint32_t)xr[lane] : 0u;
-        part = xv;
-        for (int e = lane + WAVE; e < d; e += WAVE) part += xr[e];
+    // A wave serves the entries rank, rank + nwaves, ... of its sub-queue.  It reads them 64 at a time (one entry
+    // per lane, one load), so that an item costs one memory round trip -- the vector's bytes and its origin, which
+    // depend on the entry alone -- and requests that round trip two items ahead of the one it is searching.
+    struct Item {
+        int64_t nrow, nout;         // position of the row in `blocks`; vector index the results are written at
+        uint32_t xv, part;          // the lane's row byte; the lane's share of the element sum
     };
-    int64_t nrow_next = 0, n_next = 0;
-    uint32_t xv_next = 0, part_next = 0;
-    if (rank < count) fetch(rank, nrow_next, n_next, xv_next, part_next);
-    for (uint32_t i0 = rank; i0 < count; i0 += nwaves) {
-        const int64_t nrow = nrow_next, n = n_next;
-        const uint32_t xv0 = xv_next;
-        uint32_t part = part_next;
-        fetch(i0 + nwaves, nrow_next, n_next, xv_next, part_next);
-        const uint8_t *xrow = blocks + (size_t)nrow * d;
-        // element sum of the vector in the fixed-point units of the codebook rows
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, WAVE);
-        const uint32_t sx = part << shift;
-        double best = __builtin_huge_val();
-        int bidx = 0x7fffffff;
-        // one pass: 256 consecutive positions of the sorted codebook from p0 on (lane's positions p0 + 64 q +
-        // lane, q = 0 .. 3; those outside [0, K) do not count), codeword bias[p], exact distance in
-        // sequential fp64.  Loads are issued eight elements x four codewords at a time; the additions
-        // stay in element order, one chain per codeword.
-        auto pass = [&](int p0) {
-            int kk[4], pp[4];                                   // codeword index; (clamped) sorted position
-            bool on[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int pq = p0 + q * WAVE + lane;
-                on[q] = pq >= 0 && pq < K;
-                pp[q] = pq < 0 ? 0 : (pq < K ? pq : K - 1);       // clamped: loads stay in bounds
-                kk[q] = (int)(bias[pp[q]] & 0x7fffffffu);
-            }
-            double acc[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int ebase = 0; ebase < d; ebase += WAVE) {
-                const int ecount = d - ebase < WAVE ? d - ebase : WAVE;
-                uint32_t xv = xv0;
-                if (ebase > 0) xv = lane < ecount ? (uint32_t)xrow[ebase + lane] : 0u;
-                int e0 = 0;
-                for (; e0 + 8 <= ecount; e0 += 8) {
-                    double c[8][4];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const size_t off = (size_t)(ebase + e0 + j) * K;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) c[j][q] = LDS_CB ? s_cbT[off + pp[q]] : cbT[off + pp[q]];
-                    }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const double xe = (double)__builtin_amdgcn_readlane(xv, e0 + j);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) acc[q] += fabs(xe - c[j][q]);
-                    }
-                }
-                for (; e0 < ecount; ++e0) {
-                    const size_t off = (size_t)(ebase + e0) * K;
-                    const double xe = (double)__builtin_amdgcn_readlane(xv, e0);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[q] += fabs(xe - (LDS_CB ? s_cbT[off + pp[q]] : cbT[off + pp[q]]));
-                }
-            }
-            double cd = __builtin_huge_val();
-            int ci = 0x7fffffff;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (on[q] && (acc[q] < cd || (acc[q] == cd && kk[q] < ci))) {
-                    cd = acc[q];
-                    ci = kk[q];
-                }
-            }
-            wave_argmin(cd, ci);                                // lexicographic (distance, codeword index)
-            if (cd < best || (cd == best && ci < bidx)) {
-                best = cd;
-                bidx = ci;
-            }
-        };
-        constexpr int PASS = 4 * WAVE;
-        int lo_done = (int)postab[sx >> tshift] - PASS / 2;     // first pass: the 256 positions around the vector's sum
-        if (lo_done > K - PASS) lo_done = K - PASS;
-        if (lo_done < 0) lo_done = 0;
-        int hi_done = lo_done + PASS;
-        pass(lo_done);
-        for (;;) {
-            // positions that can still hold a codeword no further away than `best`
-            const double t = ceil(best * scale) + (double)emax + 1.0;
-            const uint32_t thr = t < 4.0e9 ? (uint32_t)t : 0xffffffffu;
-            const uint32_t lo_sum = sx > thr ? sx - thr : 0u;
-            unsigned long long ih = (((unsigned long long)sx + thr) >> tshift) + 1ull;
-            if (ih > nt + 1ull) ih = nt + 1ull;
-            const int klo = (int)postab[lo_sum >> tshift];
-            const int khi = (int)postab[ih];
-            if (klo < lo_done) {
-                lo_done -= PASS;
-                pass(lo_done);
-            } else if (khi > hi_done) {
-                pass(hi_done);
-                hi_done += PASS;
-            } else {
-                break;
-            }
+    auto fetch = [=](uint32_t entry) {
+        Item it;
+        it.nrow = (int64_t)entry;                               // wave-uniform
+        it.nrow = it.nrow < N ? it.nrow : N - 1;
+        it.nout = it.nrow;
+        if (perm) {                                             // `blocks` is the sorted copy: origin inside the window
+            it.nout = (it.nrow & ~(int64_t)(SORT_WIN - 1)) + (int64_t)perm[it.nrow];
+            it.nout = it.nout < N ? it.nout : N - 1;
         }
-        if (lane == 0) {
-            labels[n] = bidx;
-            if (min_dist) min_dist[n] = best;
-        }
-        if (sums) {
-            for (int e = lane; e < d; e += WAVE) {
-                const unsigned v = xrow[e];
-                if (v) atomicAdd(&sums[(size_t)bidx * d + e], (unsigned long long)v);
+        const uint8_t *xr = blocks + (size_t)it.nrow * d;
+        it.xv = lane < d ? (uint32_t)xr[lane] : 0u;
+        it.part = it.xv;
+        for (int e = lane + WAVE; e < d; e += WAVE) it.part += xr[e];
+        return it;
+    };
+    const uint32_t mine = count > rank ? (count - rank + nwaves - 1) / nwaves : 0u;     // entries this wave serves
+    for (uint32_t c0 = 0; c0 < mine; c0 += WAVE) {
+        const uint32_t in_chunk = mine - c0 < (uint32_t)WAVE ? mine - c0 : (uint32_t)WAVE;
+        const uint32_t qidx = rank + (c0 + (uint32_t)lane) * nwaves;
+        const uint32_t entries = queue[(uint32_t)lane < in_chunk ? qidx : rank];            // (rank < count here)
+        Item it_a = fetch(__builtin_amdgcn_readlane(entries, 0));
+        Item it_b = fetch(__builtin_amdgcn_readlane(entries, in_chunk > 1 ? 1 : 0));
+        for (uint32_t j = 0; j < in_chunk; ++j) {
+            const Item cur = it_a;
+            it_a = it_b;
+            it_b = fetch(__builtin_amdgcn_readlane(entries, j + 2 < in_chunk ? (int)(j + 2) : 0));
+            const int64_t nrow = cur.nrow, n = cur.nout;
+            const uint32_t xv0 = cur.xv;
+            uint32_t part = cur.part;
+            const uint8_t *xrow = blocks + (size_t)nrow * d;
+            // element sum of the vector in the fixed-point units of the codebook rows
+    #pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, WAVE);
+            const uint32_t sx = part << shift;
+            double best = __builtin_huge_val();
+            int bidx = 0x7fffffff;
+            // one pass: 256 consecutive positions of the sorted codebook from p0 on (lane's positions p0 + 64 q +
+            // lane, q = 0 .. 3; those outside [0, K) do not count), codeword bias[p], exact distance in
+            // sequential fp64.  Loads are issued eight elements x four codewords at a time; the additions
+            // stay in element order, one chain per codeword.
+            auto pass = [&](int p0) {
+                int kk[4], pp[4];                                   // codeword index; (clamped) sorted position
+                bool on[4];
+    #pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int pq = p0 + q * WAVE + lane;
+                    on[q] = pq >= 0 && pq < K;
+                    pp[q] = pq < 0 ? 0 : (pq < K ? pq : K - 1);       // clamped: loads stay in bounds
+                    kk[q] = (int)(bias[pp[q]] & 0x7fffffffu);
+                }
+                double acc[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int ebase = 0; ebase < d; ebase += WAVE) {
+                    const int ecount = d - ebase < WAVE ? d - ebase : WAVE;
+                    uint32_t xv = xv0;
+                    if (ebase > 0) xv = lane < ecount ? (uint32_t)xrow[ebase + lane] : 0u;
+                    int e0 = 0;
+                    for (; e0 + 8 <= ecount; e0 += 8) {
+                        double c[8][4];
+    #pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const size_t off = (size_t)(ebase + e0 + j) * K;
+    #pragma unroll
+                            for (int q = 0; q < 4; ++q) c[j][q] = LDS_CB ? s_cbT[off + pp[q]] : cbT[off + pp[q]];
+                        }
+    #pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const double xe = (double)__builtin_amdgcn_readlane(xv, e0 + j);
+    #pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[q] += fabs(xe - c[j][q]);
+                        }
+                    }
+                    for (; e0 < ecount; ++e0) {
+                        const size_t off = (size_t)(ebase + e0) * K;
+                        const double xe = (double)__builtin_amdgcn_readlane(xv, e0);
+    #pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[q] += fabs(xe - (LDS_CB ? s_cbT[off + pp[q]] : cbT[off + pp[q]]));
+                    }
+                }
+                double cd = __builtin_huge_val();
+                int ci = 0x7fffffff;
+    #pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (on[q] && (acc[q] < cd || (acc[q] == cd && kk[q] < ci))) {
+                        cd = acc[q];
+                        ci = kk[q];
+                    }
+                }
+                wave_argmin(cd, ci);                                // lexicographic (distance, codeword index)
+                if (cd < best || (cd == best && ci < bidx)) {
+                    best = cd;
+                    bidx = ci;
+                }
+            };
+            constexpr int PASS = 4 * WAVE;
+            int lo_done = (int)postab[sx >> tshift] - PASS / 2;     // first pass: the 256 positions around the vector's sum
+            if (lo_done > K - PASS) lo_done = K - PASS;
+            if (lo_done < 0) lo_done = 0;
+            int hi_done = lo_done + PASS;
+            pass(lo_done);
+            for (;;) {
+                // positions that can still hold a codeword no further away than `best`
+                const double t = ceil(best * scale) + (double)emax + 1.0;
+                const uint32_t thr = t < 4.0e9 ? (uint32_t)t : 0xffffffffu;
+                const uint32_t lo_sum = sx > thr ? sx - thr : 0u;
+                unsigned long long ih = (((unsigned long long)sx + thr) >> tshift) + 1ull;
+                if (ih > nt + 1ull) ih = nt + 1ull;
+                const int klo = (int)postab[lo_sum >> tshift];
+                const int khi = (int)postab[ih];
+                if (klo < lo_done) {
+                    lo_done -= PASS;
+                    pass(lo_done);
+                } else if (khi > hi_done) {
+                    pass(hi_done);
+                    hi_done += PASS;
+                } else {
+                    break;
+                }
             }
-            if (lane == 0) atomicAdd(&counts[bidx], 1ull);
+            if (lane == 0) {
+                labels[n] = bidx;
+                if (min_dist) min_dist[n] = best;
+            }
+            if (sums) {
+                for (int e = lane; e < d; e += WAVE) {
+                    const unsigned v = xrow[e];
+                    if (v) atomicAdd(&sums[(size_t)bidx * d + e], (unsigned long long)v);
+                }
+                if (lane == 0) atomicAdd(&counts[bidx], 1ull);
+            }
         }
     }
 }
@@ -2433,7 +2525,7 @@ int launch_assign_fast_t(const AssignArgs &a, const uint32_t *c16, const uint32_
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, st, a, c16, bias);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, st, a, c16, bias, a.cb);
     LAUNCH_CHECK("k_assign_fast");
     return VQ_OK;
 }
@@ -2710,7 +2802,7 @@ int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int
     if (grid < 1) grid = 1;
 
     AssignArgs a;
-    a.blocks = blocks; a.N = N; a.d = d; a.cb = cb; a.K = K; a.kbits = kbits; a.hdr = hdr;
+    a.blocks = blocks; a.N = N; a.d = d; a.cb = cb; a.cbT = cbT; a.K = K; a.kbits = kbits; a.hdr = hdr;
     a.labels = labels; a.min_dist = min_dist;
     a.queue = queue; a.qcount = qcount; a.qcap = qcap;
     a.acc_rep = nullptr;
@@ -2752,6 +2844,14 @@ int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int
     }
     if (rc) return rc;
     if (!do_fixup) return VQ_OK;
+    if (resolves_in_kernel(dp2, lds_cw, prune)) {              // the filter left nothing queued
+        if (sums) {
+            hipLaunchKernelGGL(k_reduce_replicas, dim3((K * (d + 1) + 255) / 256), dim3(256), 0, st, a.acc_rep, K, d, sums,
+                               counts, g_gate);
+            LAUNCH_CHECK("k_reduce_replicas");
+        }
+        return VQ_OK;
+    }
     // the fix-up reads the rows the queue entries point at: the sorted copy after a pruned search
     const uint8_t *fx_rows = prune ? a.rows : blocks;
     const uint16_t *fx_perm = prune ? a.perm : nullptr;

@@ -203,13 +203,14 @@ class HipEngine:
         return (labels, mind) if want_dist else labels
 
     def search_statistics(self, prepared, N):
-        """(vectors queued for the fp64 fix-up, (vector, codeword) pairs evaluated) of the last filter pass
-        that used this prepared workspace on N vectors."""
+        """(vectors re-checked in fp64 -- queued for the fix-up kernel, or settled inside the filter kernel by the
+        variants that do that --, (vector, codeword) pairs evaluated) of the last filter pass that used this
+        prepared workspace on N vectors."""
         cb, ws = prepared
         K, d = cb.shape
         off = lib.vq_workspace_counters_offset(int(K), int(d), int(N))
         slots = ws[off: off + 64 * 64].clone()
-        queued = slots.view(torch.int32).reshape(64, 16)[:, 0].to(torch.int64).sum()
+        queued = slots.view(torch.int32).reshape(64, 16)[:, :2].to(torch.int64).sum()
         pairs = slots.view(torch.int64).reshape(64, 8)[:, 1].sum()
         return int(queued.item()), int(pairs.item())
 
