@@ -135,6 +135,7 @@ inline void hipLaunchKernelGGL(K kern, dim3 grid, dim3 block, size_t lds, hipStr
     emu::launch(grid, block, lds, [=] { kern(args...); });
 }
 inline void __syncthreads() { emu::g_block->bar.wait(); }
+inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 
 // ---- cross-lane operations -------------------------------------------------------------------------
 template <class T> inline T __shfl_xor(T v, int mask, int = 64) { return emu::lane_read(v, emu::lane() ^ mask); }

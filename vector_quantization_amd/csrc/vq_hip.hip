@@ -477,6 +477,24 @@ __global__ __launch_bounds__(256) void k_finalize(const unsigned long long *__re
     }
 }
 
+// The stop rule of VQ_Full.py:89-98 for iteration `iter` of a stage (one thread): the distortion D = dist_sum /
+// n_total is recorded, and the stage stops when |prev - D| / prev < threshold.
+__device__ __forceinline__ void apply_stop_rule(LbgState *state, double dist_sum, double n_total, double threshold,
+                                                int iter) {
+    const double D = dist_sum / n_total;
+    const double prev = state->prev;
+    uint32_t conv = 0;
+    if (prev != __builtin_huge_val()) {
+        const double change = fabs(prev - D) / prev;
+        conv = change < threshold ? 1u : 0u;
+    }
+    state->rec[iter].distortion = D;
+    state->rec[iter].converged = conv;
+    state->rec[iter].valid = 1u;
+    state->prev = D;
+    if (conv) state->stopped_after = iter;                    // later iterations of this stage are gated off
+}
+
 // Centroid update in place plus the stop rule (VQ_Full.py:81-98), for iteration g.iter of a stage: cb[k] =
 // sums[k] / counts[k] for non-empty clusters (empty ones keep their codeword); thread 0 of workgroup 0 turns
 // the distance sum into the distortion D = sum / n_total, records it, and applies the rule
@@ -491,20 +509,7 @@ __global__ __launch_bounds__(256) void k_finalize_rule(const unsigned long long 
         unsigned long long c = counts[i / d];
         if (c) cb[i] = (double)sums[i] / (double)c;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const double D = state->dist_sum / n_total;
-        const double prev = state->prev;
-        uint32_t conv = 0;
-        if (prev != __builtin_huge_val()) {
-            const double change = fabs(prev - D) / prev;
-            conv = change < threshold ? 1u : 0u;
-        }
-        state->rec[g.iter].distortion = D;
-        state->rec[g.iter].converged = conv;
-        state->rec[g.iter].valid = 1u;
-        state->prev = D;
-        if (conv) state->stopped_after = g.iter;          // later iterations of this stage are gated off
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) apply_stop_rule(state, state->dist_sum, n_total, threshold, g.iter);
 }
 
 // Zeroes up to four regions (16-byte aligned starts, sizes multiples of 16 bytes) in one launch.
@@ -2044,43 +2049,49 @@ __device__ __forceinline__ double np_leaf_sum(const double *__restrict__ a, int 
 // eight interleaved partial sums r[j] = a[j] + a[8+j] + ... (16 terms, in order), combined as
 // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)).  Eight lanes own one leaf (lane j owns r[j]); the combine is
 // the xor-1,2,4 shuffle tree.  The recursive halving above the leaves is a balanced binary tree
-// over adjacent leaves: the xor tree over the 64 leaf sums.
+// over adjacent leaves: the xor tree over the 64 leaf sums.  (All 512 threads of the workgroup call.)
+__device__ __forceinline__ void npsum_chunk(const double *__restrict__ v, int64_t c, double *__restrict__ chunk_sums,
+                                            double *s_leaf) {
+    const int tid = threadIdx.x;
+    const int j = tid & 7, leaf = tid >> 3;                    // 64 leaves x 8 lanes
+    const double *a = v + c * NP_CHUNK + (int64_t)leaf * 128 + j;
+    double t[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] = a[8 * i];
+    double r = t[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) r += t[i];
+    r += __shfl_xor(r, 1, WAVE);
+    r += __shfl_xor(r, 2, WAVE);
+    r += __shfl_xor(r, 4, WAVE);
+    if (j == 0) s_leaf[leaf] = r;
+    __syncthreads();
+    if (tid < WAVE) {
+        double u = s_leaf[tid];
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) u += __shfl_xor(u, off, WAVE);
+        if (tid == 0) chunk_sums[c] = u;
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(512) void k_npsum_chunks(const double *__restrict__ v, int64_t nfull,
                                                       double *__restrict__ chunk_sums) {
     __shared__ double s_leaf[64];
-    const int tid = threadIdx.x;
-    const int j = tid & 7, leaf = tid >> 3;                    // 64 leaves x 8 lanes
-    for (int64_t c = blockIdx.x; c < nfull; c += gridDim.x) {
-        const double *a = v + c * NP_CHUNK + (int64_t)leaf * 128 + j;
-        double t[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) t[i] = a[8 * i];
-        double r = t[0];
-#pragma unroll
-        for (int i = 1; i < 16; ++i) r += t[i];
-        r += __shfl_xor(r, 1, WAVE);
-        r += __shfl_xor(r, 2, WAVE);
-        r += __shfl_xor(r, 4, WAVE);
-        if (j == 0) s_leaf[leaf] = r;
-        __syncthreads();
-        if (tid < WAVE) {
-            double u = s_leaf[tid];
-#pragma unroll
-            for (int off = 1; off < WAVE; off <<= 1) u += __shfl_xor(u, off, WAVE);
-            if (tid == 0) chunk_sums[c] = u;
-        }
-        __syncthreads();
-    }
+    for (int64_t c = blockIdx.x; c < nfull; c += gridDim.x) npsum_chunk(v, c, chunk_sums, s_leaf);
 }
 
-// One workgroup: the trailing partial chunk (m = N mod 8192 elements, numpy's uneven recursive
-// halving reproduced with an explicit stack), then the left-to-right sum over all chunk sums.
-__global__ __launch_bounds__(1024) void k_npsum_final(const double *__restrict__ v, int64_t N, int64_t nfull,
-                                                      double *__restrict__ chunk_sums, double *__restrict__ out) {
+// One workgroup of BLOCK threads: the trailing partial chunk (m = N mod 8192 elements, numpy's uneven recursive
+// halving reproduced with an explicit stack), then the left-to-right sum over all chunk sums, returned in
+// thread 0.
+template <int BLOCK>
+__device__ __forceinline__ double npsum_final_block(const double *__restrict__ v, int64_t N, int64_t nfull,
+                                                    double *chunk_sums) {
+    static_assert(BLOCK >= 160, "one thread per leaf of the partial chunk");
     __shared__ int s_off[160], s_len[160];
     __shared__ double s_leaf[160];
     __shared__ int s_nleaf;
-    __shared__ double s_buf[1024];
+    __shared__ double s_buf[BLOCK];
     __shared__ int s_sn[20], s_sstate[20];
     __shared__ double s_sleft[20];
     const int m = (int)(N - nfull * NP_CHUNK);
@@ -2135,23 +2146,75 @@ __global__ __launch_bounds__(1024) void k_npsum_final(const double *__restrict__
                 }
             }
             chunk_sums[nfull] = ret;
+            s_leaf[0] = ret;                                    // (kept for the sum below)
         }
         __syncthreads();
     }
-    // left-to-right sum of the chunk sums, staged through LDS 1024 at a time
+    // left-to-right sum of the chunk sums, staged through LDS BLOCK at a time
     const int64_t nchunks = nfull + (m > 0 ? 1 : 0);
+    const double *cs = chunk_sums;
     double total = 0.0;
-    for (int64_t lo = 0; lo < nchunks; lo += 1024) {
+    for (int64_t lo = 0; lo < nchunks; lo += BLOCK) {
         const int64_t i = lo + threadIdx.x;
-        s_buf[threadIdx.x] = i < nchunks ? chunk_sums[i] : 0.0;
+        s_buf[threadIdx.x] = i < nfull ? cs[i] : (i < nchunks ? s_leaf[0] : 0.0);
         __syncthreads();
         if (threadIdx.x == 0) {
-            const int cnt = (int)(nchunks - lo < 1024 ? nchunks - lo : 1024);
+            const int cnt = (int)(nchunks - lo < BLOCK ? nchunks - lo : BLOCK);
             for (int j = 0; j < cnt; ++j) total += s_buf[j];
         }
         __syncthreads();
     }
+    return total;
+}
+
+__global__ __launch_bounds__(1024) void k_npsum_final(const double *__restrict__ v, int64_t N, int64_t nfull,
+                                                      double *__restrict__ chunk_sums, double *__restrict__ out) {
+    const double total = npsum_final_block<1024>(v, N, nfull, chunk_sums);
     if (threadIdx.x == 0) out[0] = total;
+}
+
+// The tail of an LBG iteration in two launches (everything of VQ_Full.py:81-98 that follows the assignment when
+// the search accumulated into the replica tables).  k_lbg_fold: every workgroup folds its share of the replica
+// tables into sums / counts -- leaving the replicas zeroed for the next iteration -- and sums its 8192-element
+// chunks of the winning distances.  k_lbg_finish (one workgroup): the chunk sums in numpy's order, the centroid
+// update in place and the stop rule.
+__global__ __launch_bounds__(512) void k_lbg_fold(const double *__restrict__ min_dist, int64_t nfull,
+                                                  double *__restrict__ chunk_sums, unsigned long long *__restrict__ rep,
+                                                  int K, int d, unsigned long long *__restrict__ sums,
+                                                  unsigned long long *__restrict__ counts, Gate g) {
+    __shared__ double s_leaf[64];
+    if (gate_closed(g)) return;
+    const int tid = threadIdx.x;
+    const int tabn = K * (d + 1);
+    for (int i = blockIdx.x * 512 + tid; i < tabn; i += gridDim.x * 512) {
+        unsigned long long t = 0;
+#pragma unroll 8
+        for (int r = 0; r < NREP; ++r) {
+            t += rep[(size_t)r * tabn + i];
+            rep[(size_t)r * tabn + i] = 0ull;
+        }
+        const int kk = i / (d + 1), e = i - kk * (d + 1);
+        if (e < d) sums[(size_t)kk * d + e] = t;
+        else counts[kk] = t;
+    }
+    for (int64_t c = blockIdx.x; c < nfull; c += gridDim.x) npsum_chunk(min_dist, c, chunk_sums, s_leaf);
+}
+
+__global__ __launch_bounds__(1024) void k_lbg_finish(const double *__restrict__ min_dist, int64_t N, int64_t nfull,
+                                                     double *__restrict__ chunk_sums,
+                                                     const unsigned long long *__restrict__ sums,
+                                                     const unsigned long long *__restrict__ counts, double *cb, int K,
+                                                     int d, double n_total, double threshold, LbgState *state, Gate g) {
+    if (gate_closed(g)) return;
+    const double total = npsum_final_block<1024>(min_dist, N, nfull, chunk_sums);
+    for (int i = threadIdx.x; i < K * d; i += 1024) {
+        const unsigned long long c = counts[i / d];
+        if (c) cb[i] = (double)sums[i] / (double)c;
+    }
+    if (threadIdx.x == 0) {
+        state->dist_sum = total;
+        apply_stop_rule(state, total, n_total, threshold, g.iter);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2651,7 +2714,17 @@ int check_common(const void *blocks, int64_t N, int d, const void *cb, int K, bo
     return VQ_OK;
 }
 
+// What the last vq_lbg_iterate of the calling thread left in a workspace: replica tables already zeroed for the
+// next iteration.  Every entry point that takes a workspace comes through check_ws, which forgets it.
+struct TailLeft {
+    const void *ws;
+    const void *state;
+    int iteration, K, d;
+};
+thread_local TailLeft g_tail_left = {nullptr, nullptr, 0, 0, 0};
+
 int check_ws(const void *ws, size_t ws_bytes, int K, int d, int64_t N) {
+    g_tail_left = TailLeft{nullptr, nullptr, 0, 0, 0};
     size_t need = ws_layout(K, d, N).total;
     if (!ws || ws_bytes < need) return fail(VQ_E_WORKSPACE, "workspace of %zu bytes needed, %zu given", need, ws_bytes);
     return VQ_OK;
@@ -3327,8 +3400,52 @@ int vq_lbg_iterate(const uint8_t *blocks, const void *sorted, size_t sorted_byte
         GateScope(const int32_t *p, int it) { g_gate = Gate{p, it}; }
         ~GateScope() { g_gate = Gate{nullptr, 0}; }
     } scope(&S->stopped_after, iteration);
+    // what the previous call on this thread left behind is read before check_ws forgets it
+    const bool chained = g_tail_left.ws == ws && g_tail_left.state == state && g_tail_left.iteration + 1 == iteration &&
+                         g_tail_left.K == K && g_tail_left.d == d;
     int rc = check_ws(ws, ws_bytes, K, d, N);
     if (rc) return rc;
+    // The fused form: the search accumulates into the replica tables, k_lbg_fold and k_lbg_finish do the rest.
+    // The fold leaves the replica tables zeroed, so only the first iteration of a run of consecutive calls
+    // (same workspace, same state, iteration numbers counting up, no other call on the workspace in between)
+    // zeroes them.
+    const bool fused = N > 0 && mode == VQ_MODE_FAST && fast_supported(d) && fused_acc_supported(sorted, K, d) &&
+                       labels != nullptr && min_dist != nullptr;
+    if (fused) {
+        rc = check_common(blocks, N, d, cb, K, true);
+        if (rc) return rc;
+        if (N > 0xfffffff0LL) return fail(VQ_E_UNSUPPORTED, "N=%lld exceeds 2^32 per call", (long long)N);
+        const WsLayout L0 = ws_layout(K, d, 0), LN = ws_layout(K, d, N);
+        char *w = static_cast<char *>(ws);
+        struct ZeroScope {
+            ~ZeroScope() { g_ws_zeroed = false; }
+        } zscope;
+        if (!chained) {
+            HIP_TRY(hipMemsetAsync(w + L0.acc_rep, 0, LN.cbT - LN.acc_rep, st));
+            HIP_TRY(hipMemsetAsync(w + LN.qcount, 0, (size_t)NQ * 64, st));
+        }
+        g_ws_zeroed = true;
+        rc = run_prepare(cb, K, d, ws, st);
+        if (rc) return rc;
+        rc = run_fast(blocks, sorted, sorted_bytes, N, d, cb, K, labels, min_dist, reinterpret_cast<unsigned long long *>(sums),
+                      reinterpret_cast<unsigned long long *>(counts), ws, st, 1);
+        if (rc) return rc;
+        const int64_t nfull = N / NP_CHUNK;
+        const int tabn = K * (d + 1);
+        int64_t grid = nfull > (tabn + 511) / 512 ? nfull : (tabn + 511) / 512;
+        if (grid > 4096) grid = 4096;
+        double *chunk_sums = reinterpret_cast<double *>(w + LN.chunks);
+        unsigned long long *s64 = reinterpret_cast<unsigned long long *>(sums);
+        unsigned long long *c64 = reinterpret_cast<unsigned long long *>(counts);
+        hipLaunchKernelGGL(k_lbg_fold, dim3((unsigned)grid), dim3(512), 0, st, min_dist, nfull, chunk_sums,
+                           reinterpret_cast<unsigned long long *>(w + L0.acc_rep), K, d, s64, c64, g_gate);
+        LAUNCH_CHECK("k_lbg_fold");
+        hipLaunchKernelGGL(k_lbg_finish, dim3(1), dim3(1024), 0, st, min_dist, N, nfull, chunk_sums, s64, c64, cb, K, d,
+                           (double)n_total, threshold, S, g_gate);
+        LAUNCH_CHECK("k_lbg_finish");
+        g_tail_left = TailLeft{ws, state, iteration, K, d};
+        return VQ_OK;
+    }
     // one launch zeroes the caller's sums and counts, the queue counters and the replica tables of the workspace
     // (regions that are not 16-byte multiples fall back to plain fills)
     struct ZeroScope {
