@@ -157,12 +157,14 @@ def search_profile(eng, img, bh, bw, cb, reps, device):
         eng.encode_prepared(blocks, prepared, **kw)
     filter_ms = event_ms(lambda: eng.encode_prepared(blocks, prepared, phases=1, **kw), reps, device)
     queued, pairs_eval = eng.search_statistics(prepared, N)
-    fixup_ms = event_ms(lambda: eng.encode_prepared(blocks, prepared, phases=2, **kw), reps, device)
+    in_filter = bool(pruned and eng.prune_resolves_in_filter(K, d))     # near-ties settled inside the filter kernel
+    fixup_ms = 0.0 if in_filter else event_ms(lambda: eng.encode_prepared(blocks, prepared, phases=2, **kw), reps, device)
     both_ms = event_ms(lambda: eng.encode_prepared(blocks, prepared, **kw), reps, device)
     pairs_all = float(N) * K
     pairs_eval = float(pairs_eval)
     ops_exec = 2.0 * d * pairs_eval
-    out = dict(K=K, d=d, N=N, pruned_search=bool(pruned), filter_kernel_ms=filter_ms, fixup_kernel_ms=fixup_ms,
+    out = dict(K=K, d=d, N=N, pruned_search=bool(pruned), near_ties_settled_in_filter=in_filter,
+               filter_kernel_ms=filter_ms, fixup_kernel_ms=fixup_ms,
                search_ms=both_ms, vectors_per_s=N / (both_ms * 1e-3), queued_for_fp64_frac=queued / N,
                evaluated_pair_frac=pairs_eval / pairs_all,
                executed_tops=ops_exec / (filter_ms * 1e-3) / 1e12,
@@ -219,7 +221,8 @@ def main():
     scratch = torch.empty(_lib.lib.vq_sorted_bytes(d, N), dtype=torch.uint8, device=device)
 
     def step():
-        # image -> sorted block vectors -> prepared codebook -> pruned search -> fp64 fix-up -> decode
+        # image -> sorted block vectors -> prepared codebook -> pruned search (near-ties re-checked in fp64 inside
+        # the same kernel) -> decode
         eng.encode_image(img, BH, BW, cb, scratch=scratch, labels=labels)
         return eng.decode(labels.view(nr, nc), cb, BH, BW, 1)
 
@@ -298,9 +301,11 @@ def main():
              "subtract + |.|-accumulate ops (2*d per evaluated (vector, codeword) pair; pairs counted by the kernel "
              "itself: rows each wave evaluated x its 256 vectors) / the filter kernel's mean duration (HIP events "
              "around that launch alone). peak = the v_sad_u16 issue ceiling: one wave64 instruction per 4 cycles per "
-             "SIMD (measured, profiles/r02_valu_ubench.txt; no operand form issues faster), two |x-c| accumulations "
+             "SIMD (measured, profiles/r02_valu_ubench_forms1.txt and _forms2.txt; no operand form issues faster), two |x-c| accumulations "
              "per lane = 157.3 T ops/s. Besides its d/2 SADs every pair costs 3 more instructions of the same issue "
-             "class (key, median, minimum), so 8/11 = 0.73 is the ceiling of frac at d = 16. The pruned search "
+             "class (key, median, minimum), so 8/11 = 0.73 is the ceiling of frac at d = 16; the kernel's time also "
+             "holds the fp64 re-check of its near-ties (queued_for_fp64_frac of the vectors; there is no fix-up "
+             "launch for this shape, fixup_kernel_ms = 0). The pruned search "
              "evaluates only evaluated_pair_frac of all N*K pairs (codewords whose element sum differs from the "
              "vector's by more than the best distance so far cannot win), with identical labels: that gain is "
              "algorithmic_speedup, not part of frac. " + pmc_note)
@@ -312,7 +317,7 @@ def main():
                            frac=sort_alg / (sort_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, traffic=pmc_bytes("k_window_sort"),
                            algorithmic_bytes_per_vector=2 * d + 2,
                            note="reads every pixel once, writes every row once at its sorted place plus a 2-byte origin"),
-        "decode": dict(bound="hbm", kernel="k_decode_blockrows_u8<16> (vq_decode_u8)", kernel_ms=dec_ms,
+        "decode": dict(bound="hbm", kernel="k_decode_quads (vq_decode_u8)", kernel_ms=dec_ms,
                        achieved=dec_alg / (dec_ms * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
                        frac=dec_alg / (dec_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, traffic=pmc_bytes("k_decode"),
                        algorithmic_bytes_per_vector=d + 4),

@@ -144,6 +144,9 @@ int vq_encode_l1_prepared_phases(const uint8_t *blocks, const void *sorted, size
                                  const double *cb, int K, int32_t *labels, double *min_dist, int phases, void *ws,
                                  size_t ws_bytes, void *stream);
 size_t vq_workspace_counters_offset(int K, int d, int64_t N);
+/* 1 when the pruned search of a (K, d) codebook (vq_prune_supported, `sorted` given) settles its near-ties inside
+ * the filter kernel, so that its phase 2 launches nothing; 0 when it queues them for the fix-up kernel. */
+int vq_prune_resolves_in_filter(int K, int d);
 
 /* One LBG assignment pass, fused.  Replaces VQ_Full.py:77-90 up to the division: assigns every
  * vector as vq_encode_l1 does (labels: N int32, min_dist: N doubles, both overwritten), ADDS into
@@ -170,7 +173,9 @@ int vq_lbg_accum(const uint8_t *blocks, const void *sorted, size_t sorted_bytes,
  * i: once an iteration has met the rule, the kernels of later iterations of that stage return at once
  * and leave cb and the records untouched.  Record i sits at byte 64 + 16 * i of the state:
  * { double distortion; uint32 converged; uint32 valid } -- valid = 0 marks an iteration that was skipped.
- * A negative threshold never converges (forced iteration counts). */
+ * A negative threshold never converges (forced iteration counts).  Consecutive iterations of a stage that use
+ * the same ws and state, with no other entry point given that ws in between, skip re-zeroing the tables of ws
+ * (the previous iteration leaves them zeroed); any other call sequence is detected and costs one extra fill. */
 size_t vq_lbg_state_bytes(int max_iterations);
 int vq_lbg_stage_begin(void *state, size_t state_bytes, int max_iterations, void *stream);
 int vq_lbg_iterate(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d, double *cb, int K,

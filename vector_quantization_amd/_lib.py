@@ -41,6 +41,7 @@ SIGNATURES = {
     "vq_codebook_prepare": (_i, [_vp, _i, _i, _vp, _sz, _vp]),
     "vq_sorted_bytes": (_sz, [_i, _i64]),
     "vq_prune_supported": (_i, [_i, _i]),
+    "vq_prune_resolves_in_filter": (_i, [_i, _i]),
     "vq_blocks_sort": (_i, [_vp, _i64, _i, _vp, _sz, _vp]),
     "vq_blocks_sort_img": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "vq_encode_l1_img": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),

@@ -3215,6 +3215,12 @@ size_t vq_sorted_bytes(int d, int64_t N) {
 
 int vq_prune_supported(int K, int d) { return (K > 0 && d > 0 && prune_supported(K, d)) ? 1 : 0; }
 
+int vq_prune_resolves_in_filter(int K, int d) {
+    if (K <= 0 || d <= 0 || !prune_supported(K, d)) return 0;
+    const int dp2 = dp2_bucket(d);
+    return resolves_in_kernel(dp2, !prune_by_scalar_loads(K, dp2), true) ? 1 : 0;
+}
+
 int vq_blocks_sort(const uint8_t *blocks, int64_t N, int d, void *sorted, size_t sorted_bytes, void *stream) {
     if (N < 0 || d <= 0) return fail(VQ_E_INVALID, "need N >= 0 and d > 0");
     if (N == 0) return VQ_OK;

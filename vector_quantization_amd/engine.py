@@ -151,6 +151,10 @@ class HipEngine:
     def prune_supported(K, d):
         return bool(lib.vq_prune_supported(int(K), int(d)))
 
+    def prune_resolves_in_filter(self, K, d):
+        """Whether the pruned search of this shape settles near-ties inside its filter kernel (no fix-up launch)."""
+        return bool(lib.vq_prune_resolves_in_filter(int(K), int(d)))
+
     def encode(self, blocks, cb, want_dist=False, mode=None, sorted=None, shape=None):
         """blocks may be None when `sorted` serves the codebook's shape (prune_supported); `shape` = (N, d)
         then says what the sorted copy holds."""
