@@ -84,10 +84,11 @@ def test_emu_encode_full_search(eng, oracle, K, d, N):
 
 
 @pytest.mark.parametrize("K,d,N", [(64, 16, 3000), (32, 4, 2000), (100, 11, 1500), (256, 16, 2048), (2048, 4, 2500),
-                                   (500, 32, 1300)])
+                                   (500, 32, 1300), (700, 16, 1200), (400, 6, 800)])
 def test_emu_encode_pruned(eng, oracle, K, d, N):
     rng = np.random.default_rng(K * 3 + d)
     blocks, cb = _structured(rng, K, d, N)
+    cb[K // 3] = cb[1]                                               # duplicate row
     want_l, want_d = oracle.encode_l1(blocks, cb, want_dist=True)
     b = T(blocks)
     got_l, got_d = eng.encode(b, T(cb), want_dist=True, mode=1, sorted=eng.sort_blocks(b))

@@ -578,6 +578,11 @@ __device__ __forceinline__ uint32_t prep_ceil_sat(double c) {       // ceil, sat
 // SMALL (d <= 16 and K <= 1024, the shapes of the LBG stages of small blocks): one codeword per thread, held
 // in registers from the single read of the codebook to the writes at its sorted place -- one memory round
 // trip instead of five.
+#ifdef VQ_PREP_STAMPS
+#define PREP_STAMP(i) do { if (threadIdx.x == 0) stamps[i] = wall_clock64(); } while (0)
+#else
+#define PREP_STAMP(i) do { } while (0)
+#endif
 template <bool SMALL>
 __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb, int K, int d, int dp2, uint32_t clim,
                                                   PrepHeader *__restrict__ hdr, uint32_t *__restrict__ c16,
@@ -586,6 +591,10 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
     extern __shared__ __align__(16) unsigned long long s_keys[];
     __shared__ uint32_t s_cmax;
     __shared__ uint32_t s_emax;
+#ifdef VQ_PREP_STAMPS
+    __shared__ unsigned long long stamps[8];
+#endif
+    PREP_STAMP(0);
     __shared__ __align__(16) uint32_t s_sc[PREP_SORT_CAP + 4];   // element sum of each fixed-point row, original order
     // the same sums in ascending order: written after the duplicate scan is over, into the space of its hash
     // table (K <= PREP_SORT_CAP codebooks get at least K * 4 bytes of dynamic LDS)
@@ -608,6 +617,7 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
         s_first[i] = 0xffffffffu;
     }
     __syncthreads();
+    PREP_STAMP(1);
     // phase A: largest entry
     const int64_t n = (int64_t)K * d;
     uint32_t lmax = 0;
@@ -629,6 +639,7 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
     }
     atomicMax(&s_cmax, lmax);
     __syncthreads();
+    PREP_STAMP(2);
     const uint32_t cmax = s_cmax;
     // largest scale 2^s (s <= 8) that keeps both the pixels (<= 255) and the largest codebook entry
     // within clim, the fixed-point limit the key layout allows
@@ -699,6 +710,7 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
         }
     }
     __syncthreads();
+    PREP_STAMP(3);
     // phase C: row k is a duplicate when the first row with its hash is an earlier, bit-identical
     // row.  Identical rows give identical distances, so the later one can never win (ties go to the
     // lower index) and gets the never-competes bit.  A missed duplicate only costs re-checks.
@@ -729,6 +741,7 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
         }
     }
     __syncthreads();                                             // the hash table is free: s_scs may be written
+    PREP_STAMP(4);
     // phase D: position of the row in ascending (element sum, index) order, by counting
     {
         int it = 0;
@@ -777,6 +790,7 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
     const uint32_t nt = (mtab >> tshift) + 1u;                 // entries 0 .. nt cover every vector sum
     if (do_sort) {
         __syncthreads();
+        PREP_STAMP(5);
         for (uint32_t t = threadIdx.x; t <= nt + 1u; t += blockDim.x) {
             uint32_t lo = 0, hi = (uint32_t)K;                 // lower bound of (t << tshift) in s_scs
             const uint64_t target = (uint64_t)t << tshift;
@@ -792,6 +806,196 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
         hdr->emax = s_emax;
         hdr->cmax = cmax;
         hdr->sorted = do_sort ? 1u : 0u;
+        hdr->tshift = tshift;
+        hdr->nt = nt;
+    }
+#ifdef VQ_PREP_STAMPS
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t6 = wall_clock64();
+        printf("prep stamps (10 ns ticks): init %llu A %llu B %llu C %llu D %llu tab %llu\n", stamps[1] - stamps[0],
+               stamps[2] - stamps[1], stamps[3] - stamps[2], stamps[4] - stamps[3], stamps[5] - stamps[4], t6 - stamps[5]);
+    }
+#endif
+}
+
+// Codebook preparation for short rows and small codebooks (d <= 16, K * TPC <= 1024: the LBG stages of small
+// blocks, where this launch sits on the critical path of every iteration).  Same outputs as k_prepare, with TPC
+// adjacent threads per codeword: each holds 16 / TPC entries in registers from the single read of the
+// codebook to the writes at the sorted place, partial sums are combined across the TPC lanes, and the ranking
+// scan is split between them.  Global stores come last, so that nothing waits for them.
+template <int TPC>
+__global__ __launch_bounds__(1024) void k_prepare_small(const double *__restrict__ cb, int K, int d, int dp2,
+                                                        uint32_t clim, PrepHeader *__restrict__ hdr,
+                                                        uint32_t *__restrict__ c16, uint32_t *__restrict__ bias,
+                                                        double *__restrict__ cbT, uint32_t *__restrict__ postab) {
+    extern __shared__ __align__(16) unsigned long long s_keys[];
+    __shared__ uint32_t s_cmax;
+    __shared__ uint32_t s_emax;
+    __shared__ __align__(16) uint32_t s_sc[1024 + 4];            // element sum of each fixed-point row, original order
+    constexpr int EPT = 16 / TPC;                                // entries per thread
+    constexpr int PPT = EPT / 2;                                 // fixed-point words per thread
+    uint32_t *s_scs = reinterpret_cast<uint32_t *>(s_keys);      // the sums in ascending order (after the duplicate scan)
+    const bool scan_dups = K > 1;
+    const uint32_t T = scan_dups ? 2u * (uint32_t)K : 0u;        // table slots
+    unsigned long long *s_rowhash = s_keys + T;                  // K entries
+    uint32_t *s_first = reinterpret_cast<uint32_t *>(s_rowhash + (scan_dups ? K : 0));
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int k = tid / TPC, sub = tid % TPC;
+    const bool live = k < K;
+    const int kc = live ? k : K - 1;
+    if (tid == 0) {
+        s_cmax = 0;
+        s_emax = 0;
+    }
+    if (tid < 4) s_sc[K + tid] = 0xffffffffu;
+    for (uint32_t i = tid; i < T; i += 1024) {
+        s_keys[i] = 0ull;
+        s_first[i] = 0xffffffffu;
+    }
+    // phase A: this thread's entries; largest entry of the codebook
+    double creg[EPT];
+    {
+        const double *row = cb + (size_t)kc * d;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int ee = sub * EPT + e;
+            creg[e] = row[ee < d ? ee : d - 1];
+        }
+    }
+    uint32_t lmax = 0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const uint32_t m = prep_ceil_sat(creg[e]);
+        lmax = m > lmax ? m : lmax;
+    }
+    lmax = wave_reduce_u32<true>(lmax);
+    __syncthreads();                                             // s_cmax is initialised
+    if (lane == 0) atomicMax(&s_cmax, lmax);
+    __syncthreads();
+    const uint32_t cmax = s_cmax;
+    const uint64_t top = cmax > 255u ? cmax : 255u;
+    int s = 8;
+    while (s > 0 && (top << s) > (uint64_t)clim) --s;
+    const double scale = (double)(1u << s);
+    const double qmax = (double)clim;
+    // phase B: fixed-point words, rounding-error bound, element sum and row hash, combined over the TPC lanes
+    uint32_t preg[PPT];
+    double err = 0.0;
+    uint32_t sc = 0;
+    unsigned long long h = 0x243F6A8885A308D3ull + (unsigned long long)sub;
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+        uint32_t pair = 0;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+            if (sub * EPT + 2 * p + hh < d) prep_quant(creg[2 * p + hh], hh, scale, qmax, pair, err, sc, h);
+        preg[p] = pair;
+    }
+#pragma unroll
+    for (int m = 1; m < TPC; m <<= 1) {
+        err += __shfl_xor(err, m, WAVE);
+        sc += __shfl_xor(sc, m, WAVE);
+        h += __shfl_xor(h, m, WAVE);                             // (a sum: the same in every lane of the group)
+    }
+    h = mix64(h, 0x9E3779B97F4A7C15ull);
+    if (h == 0ull) h = 1ull;
+    // strict integer upper bound of err (plus slack for the fp64 rounding of err itself)
+    uint32_t ek = (err < 2.0e9) ? (uint32_t)err + 2u : 0x7fffffffu;
+    ek = wave_reduce_u32<true>(live ? ek : 0u);
+    if (lane == 0) atomicMax(&s_emax, ek);
+    if (live && sub == 0) {
+        s_sc[k] = sc;
+        // record the smallest index of each distinct row hash (0 marks an empty slot)
+        if (scan_dups) {
+            s_rowhash[k] = h;
+            uint32_t slot = (uint32_t)(h % T);
+            for (uint32_t probe = 0; probe < T; ++probe) {
+                unsigned long long old = atomicCAS(&s_keys[slot], 0ull, h);
+                if (old == 0ull || old == h) {
+                    atomicMin(&s_first[slot], (uint32_t)k);
+                    break;
+                }
+                slot = slot + 1 == T ? 0 : slot + 1;
+            }
+        }
+    }
+    __syncthreads();
+    // phase C: row k is a duplicate when the first row with its hash is an earlier, bit-identical row
+    uint32_t dup = 0;
+    if (scan_dups && live && sub == 0) {
+        uint32_t slot = (uint32_t)(h % T);
+        uint32_t first = 0xffffffffu;
+        for (uint32_t probe = 0; probe < T; ++probe) {
+            unsigned long long key = s_keys[slot];
+            if (key == h) {
+                first = s_first[slot];
+                break;
+            }
+            if (key == 0ull) break;
+            slot = slot + 1 == T ? 0 : slot + 1;
+        }
+        if (first < (uint32_t)k) {
+            const unsigned long long *rowb = reinterpret_cast<const unsigned long long *>(cb + (size_t)k * d);
+            const unsigned long long *rj = reinterpret_cast<const unsigned long long *>(cb + (size_t)first * d);
+            int e = 0;
+            while (e < d && rj[e] == rowb[e]) ++e;
+            if (e == d) dup = 1u;
+        }
+    }
+    __syncthreads();                                             // the hash table is free: s_scs may be written
+    // phase D: position of the row in ascending (element sum, index) order, by counting; the TPC lanes of a
+    // codeword take every TPC-th group of four sums
+    const uint32_t me = s_sc[kc];
+    uint32_t pos = 0;
+    {
+        const uint4 *sv = reinterpret_cast<const uint4 *>(s_sc);
+        for (int j4 = sub; j4 < (K + 3) / 4; j4 += TPC) {
+            const uint4 o = sv[j4];
+            const int j = 4 * j4;
+            pos += (o.x < me || (o.x == me && j < kc)) ? 1u : 0u;
+            pos += (o.y < me || (o.y == me && j + 1 < kc)) ? 1u : 0u;
+            pos += (o.z < me || (o.z == me && j + 2 < kc)) ? 1u : 0u;
+            pos += (o.w < me || (o.w == me && j + 3 < kc)) ? 1u : 0u;
+        }
+#pragma unroll
+        for (int m = 1; m < TPC; m <<= 1) pos += __shfl_xor(pos, m, WAVE);
+    }
+    if (live && sub == 0) s_scs[pos] = me;
+    __syncthreads();
+    // position table over the sums a vector can have: 0 .. d * 255 << s
+    const uint32_t mtab = (uint32_t)d * (255u << s) + 1u;
+    uint32_t tshift = 0;
+    while ((mtab >> tshift) > (uint32_t)POSTAB_NT - 1u) ++tshift;
+    const uint32_t nt = (mtab >> tshift) + 1u;                 // entries 0 .. nt cover every vector sum
+    for (uint32_t t = tid; t <= nt + 1u; t += 1024) {
+        uint32_t lo = 0, hi = (uint32_t)K;                     // lower bound of (t << tshift) in s_scs
+        const uint64_t target = (uint64_t)t << tshift;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((uint64_t)s_scs[mid] < target) lo = mid + 1; else hi = mid;
+        }
+        postab[t] = t == nt + 1u ? (uint32_t)K : lo;
+    }
+    // the fixed-point row and the transposed fp64 copy at their sorted place: c16[pos], cbT[e][pos]
+    if (live) {
+#pragma unroll
+        for (int p = 0; p < PPT; ++p)
+            if (sub * PPT + p < dp2) c16[(size_t)pos * dp2 + sub * PPT + p] = preg[p];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e)
+            if (sub * EPT + e < d) cbT[(size_t)(sub * EPT + e) * K + pos] = creg[e];
+        if (sub == 0) bias[pos] = (uint32_t)k | (dup << 31);
+    }
+    // pad rows: zeros with the never-competes bias, so that batches of codewords may run past K
+    const int kpad = (K + 7) / 8 * 8;
+    for (int i = tid; i < (kpad - K) * dp2; i += 1024) c16[(size_t)K * dp2 + i] = 0u;
+    for (int i = K + tid; i < kpad; i += 1024) bias[i] = 0x80000000u;
+    if (tid == 0) {
+        hdr->shift = (uint32_t)s;
+        hdr->emax = s_emax;
+        hdr->cmax = cmax;
+        hdr->sorted = 1u;
         hdr->tshift = tshift;
         hdr->nt = nt;
     }
@@ -2740,8 +2944,22 @@ int run_prepare(const double *cb, int K, int d, void *ws, hipStream_t st) {
     // 2K keys + K hashes + 2K indices; afterwards the first K * 4 bytes hold the sorted element sums
     const size_t hash_lds = (K <= PREP_HASH_CAP && K > 1) ? (size_t)K * 32 : 16;
     static_assert(PREP_SORT_CAP <= PREP_HASH_CAP, "sorted codebooks have a hash table to put their sums in");
-    const bool small = d <= 16 && K <= 1024;                // one codeword per thread, kept in registers
-    auto kern = small ? k_prepare<true> : k_prepare<false>;
+    PrepHeader *hdr = reinterpret_cast<PrepHeader *>(w + L.header);
+    uint32_t *c16 = reinterpret_cast<uint32_t *>(w + L.c16), *bias = reinterpret_cast<uint32_t *>(w + L.bias);
+    double *cbT = reinterpret_cast<double *>(w + L.cbT);
+    uint32_t *postab = reinterpret_cast<uint32_t *>(w + L.postab);
+    if (d <= 16 && K <= 1024) {                             // short rows, small codebooks: 4, 2 or 1 threads per codeword
+        const uint32_t clim = key_layout(K, dp2).clim;
+        if (K <= 256)
+            hipLaunchKernelGGL(k_prepare_small<4>, dim3(1), dim3(1024), hash_lds, st, cb, K, d, dp2, clim, hdr, c16, bias, cbT, postab);
+        else if (K <= 512)
+            hipLaunchKernelGGL(k_prepare_small<2>, dim3(1), dim3(1024), hash_lds, st, cb, K, d, dp2, clim, hdr, c16, bias, cbT, postab);
+        else
+            hipLaunchKernelGGL(k_prepare_small<1>, dim3(1), dim3(1024), hash_lds, st, cb, K, d, dp2, clim, hdr, c16, bias, cbT, postab);
+        LAUNCH_CHECK("k_prepare_small");
+        return VQ_OK;
+    }
+    auto kern = k_prepare<false>;
     if (hash_lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)hash_lds));
