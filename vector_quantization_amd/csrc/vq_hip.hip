@@ -93,9 +93,12 @@ constexpr int MAX_K = 1 << 20;
 #ifndef VQ_RBIG
 #define VQ_RBIG 2
 #endif
-// Pruned search: vectors per lane, codewords added per side and round.
+// Pruned search: vectors per lane, codewords per scalar-load batch (d <= 16), codewords added per side and round.
 #ifndef VQ_RP
-#define VQ_RP 4
+#define VQ_RP 2
+#endif
+#ifndef VQ_UP
+#define VQ_UP 2
 #endif
 #ifndef VQ_GP
 #define VQ_GP 16
@@ -575,15 +578,6 @@ __device__ __forceinline__ uint32_t prep_ceil_sat(double c) {       // ceil, sat
 
 // Dynamic LDS: an open-addressing table of 2*K slots (keys = 64-bit row hashes), the K row hashes,
 // then per slot the smallest row index seen for its key.
-// SMALL (d <= 16 and K <= 1024, the shapes of the LBG stages of small blocks): one codeword per thread, held
-// in registers from the single read of the codebook to the writes at its sorted place -- one memory round
-// trip instead of five.
-#ifdef VQ_PREP_STAMPS
-#define PREP_STAMP(i) do { if (threadIdx.x == 0) stamps[i] = wall_clock64(); } while (0)
-#else
-#define PREP_STAMP(i) do { } while (0)
-#endif
-template <bool SMALL>
 __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb, int K, int d, int dp2, uint32_t clim,
                                                   PrepHeader *__restrict__ hdr, uint32_t *__restrict__ c16,
                                                   uint32_t *__restrict__ bias, double *__restrict__ cbT,
@@ -591,10 +585,6 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
     extern __shared__ __align__(16) unsigned long long s_keys[];
     __shared__ uint32_t s_cmax;
     __shared__ uint32_t s_emax;
-#ifdef VQ_PREP_STAMPS
-    __shared__ unsigned long long stamps[8];
-#endif
-    PREP_STAMP(0);
     __shared__ __align__(16) uint32_t s_sc[PREP_SORT_CAP + 4];   // element sum of each fixed-point row, original order
     // the same sums in ascending order: written after the duplicate scan is over, into the space of its hash
     // table (K <= PREP_SORT_CAP codebooks get at least K * 4 bytes of dynamic LDS)
@@ -605,8 +595,6 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
     const uint32_t T = scan_dups ? 2u * (uint32_t)K : 0u;       // table slots
     unsigned long long *s_rowhash = s_keys + T;                  // K entries
     uint32_t *s_first = reinterpret_cast<uint32_t *>(s_rowhash + (scan_dups ? K : 0));
-    double creg[SMALL ? 16 : 1];                                 // SMALL: this thread's codeword
-    uint32_t preg[SMALL ? 8 : 1];                                //        and its fixed-point row
     if (threadIdx.x == 0) {
         s_cmax = 0;
         s_emax = 0;
@@ -617,29 +605,15 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
         s_first[i] = 0xffffffffu;
     }
     __syncthreads();
-    PREP_STAMP(1);
     // phase A: largest entry
     const int64_t n = (int64_t)K * d;
     uint32_t lmax = 0;
-    if constexpr (SMALL) {
-        const int kc = (int)threadIdx.x < K ? (int)threadIdx.x : K - 1;
-        const double *row = cb + (size_t)kc * d;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) creg[e] = row[e < d ? e : d - 1];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const uint32_t m = prep_ceil_sat(creg[e]);
-            lmax = m > lmax ? m : lmax;
-        }
-    } else {
-        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-            const uint32_t m = prep_ceil_sat(cb[i]);
-            lmax = m > lmax ? m : lmax;
-        }
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t m = prep_ceil_sat(cb[i]);
+        lmax = m > lmax ? m : lmax;
     }
     atomicMax(&s_cmax, lmax);
     __syncthreads();
-    PREP_STAMP(2);
     const uint32_t cmax = s_cmax;
     // largest scale 2^s (s <= 8) that keeps both the pixels (<= 255) and the largest codebook entry
     // within clim, the fixed-point limit the key layout allows
@@ -655,16 +629,7 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
         double err = 0.0;
         uint32_t sc = 0;
         unsigned long long h = 0x243F6A8885A308D3ull;
-        if constexpr (SMALL) {
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                uint32_t pair = 0;
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh)
-                    if (2 * p + hh < d) prep_quant(creg[2 * p + hh], hh, scale, qmax, pair, err, sc, h);
-                preg[p] = pair;
-            }
-        } else {
+        {
             for (int p0 = 0; p0 < dp2; p0 += 4) {
                 double c[8];
 #pragma unroll
@@ -710,7 +675,6 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
         }
     }
     __syncthreads();
-    PREP_STAMP(3);
     // phase C: row k is a duplicate when the first row with its hash is an earlier, bit-identical
     // row.  Identical rows give identical distances, so the later one can never win (ties go to the
     // lower index) and gets the never-competes bit.  A missed duplicate only costs re-checks.
@@ -741,7 +705,6 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
         }
     }
     __syncthreads();                                             // the hash table is free: s_scs may be written
-    PREP_STAMP(4);
     // phase D: position of the row in ascending (element sum, index) order, by counting
     {
         int it = 0;
@@ -764,14 +727,7 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
                 }
                 s_scs[pos] = me;
                 // the fixed-point row and the transposed fp64 copy go to their sorted place: c16[pos], cbT[e][pos]
-                if constexpr (SMALL) {
-#pragma unroll
-                    for (int p = 0; p < 8; ++p)
-                        if (p < dp2) c16[(size_t)pos * dp2 + p] = preg[p];
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        if (e < d) cbT[(size_t)e * K + pos] = creg[e];
-                } else {
+                {
                     for (int p = 0; p < dp2; ++p) c16[(size_t)pos * dp2 + p] = c16u[(size_t)k * dp2 + p];
                     for (int e = 0; e < d; ++e) cbT[(size_t)e * K + pos] = cb[(size_t)k * d + e];
                 }
@@ -790,7 +746,6 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
     const uint32_t nt = (mtab >> tshift) + 1u;                 // entries 0 .. nt cover every vector sum
     if (do_sort) {
         __syncthreads();
-        PREP_STAMP(5);
         for (uint32_t t = threadIdx.x; t <= nt + 1u; t += blockDim.x) {
             uint32_t lo = 0, hi = (uint32_t)K;                 // lower bound of (t << tshift) in s_scs
             const uint64_t target = (uint64_t)t << tshift;
@@ -809,14 +764,6 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
         hdr->tshift = tshift;
         hdr->nt = nt;
     }
-#ifdef VQ_PREP_STAMPS
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned long long t6 = wall_clock64();
-        printf("prep stamps (10 ns ticks): init %llu A %llu B %llu C %llu D %llu tab %llu\n", stamps[1] - stamps[0],
-               stamps[2] - stamps[1], stamps[3] - stamps[2], stamps[4] - stamps[3], stamps[5] - stamps[4], t6 - stamps[5]);
-    }
-#endif
 }
 
 // Codebook preparation for short rows and small codebooks (d <= 16, K * TPC <= 1024: the LBG stages of small
@@ -1529,7 +1476,7 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
         if constexpr (!LDS_CW) {
             // Codewords are fetched by scalar loads (wave-uniform addresses) in batches of U, so that
             // one scalar-memory wait is paid per U * R * (DP2 + 3) vector instructions.
-            constexpr int U = DP2 <= 8 ? VQ_U8 : (DP2 <= 16 ? 2 : 1);
+            constexpr int U = DP2 <= 8 ? (PRUNE ? VQ_UP : VQ_U8) : (DP2 <= 16 ? 2 : 1);
             // rows [lo, hi) of the fixed-point codebook, hi - lo a multiple of U (rows K .. Kpad are
             // pad rows that never win)
             auto run = [&](int lo, int hi) {
@@ -2959,7 +2906,7 @@ int run_prepare(const double *cb, int K, int d, void *ws, hipStream_t st) {
         LAUNCH_CHECK("k_prepare_small");
         return VQ_OK;
     }
-    auto kern = k_prepare<false>;
+    auto kern = k_prepare;
     if (hash_lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)hash_lds));
