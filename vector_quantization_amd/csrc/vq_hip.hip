@@ -955,6 +955,15 @@ __global__ __launch_bounds__(1024) void k_prepare_small(const double *__restrict
 struct SrcBlocks {
     const uint8_t *p;
     int d;
+    // the direct-addressing interface of k_window_sort (a vector's first byte as an offset from origin(), the
+    // offset of its w-th word from there): not used for the block matrix, whose word() is one multiply already
+    __device__ __forceinline__ bool fast_words() const { return false; }
+    __device__ __forceinline__ const uint8_t *origin() const { return p; }
+    __device__ __forceinline__ uint32_t vec_base(int64_t, bool &inside) const {
+        inside = false;
+        return 0u;
+    }
+    __device__ __forceinline__ uint32_t word_off(int) const { return 0u; }
     __device__ __forceinline__ bool quads() const { return false; }
     __device__ __forceinline__ void quad_words(int64_t, uint32_t (&)[4][4]) const {}
     __device__ __forceinline__ uint32_t byte(int64_t n, int e) const { return p[(size_t)n * d + e]; }
@@ -988,6 +997,19 @@ struct SrcImage {
     uint32_t nc, seg, d;          // blocks per block row, bytes per block row segment (bw * C), bh * seg
     int words_ok;                 // image rows are whole aligned words (W * C % 4 == 0, base aligned)
     int quads_ok;                 // 4x4 blocks of 1-byte pixels, no padding, image rows multiples of 16 aligned bytes
+    int fast32;                   // every byte offset into the image fits 32 bits
+    // direct addressing: blocks that need no padding are read at origin() + vec_base + word_off
+    __device__ __forceinline__ bool fast_words() const { return fast32 != 0 && words_ok != 0 && (seg & 3u) == 0; }
+    __device__ __forceinline__ const uint8_t *origin() const { return img; }
+    __device__ __forceinline__ uint32_t vec_base(int64_t n, bool &inside) const {
+        const uint32_t r = (uint32_t)n / nc, q = (uint32_t)n - r * nc;
+        inside = (r + 1u) * (uint32_t)bh <= (uint32_t)H && (q + 1u) * (uint32_t)bw <= (uint32_t)W;
+        return r * (uint32_t)bh * (uint32_t)(W * C) + q * seg;
+    }
+    __device__ __forceinline__ uint32_t word_off(int w) const {
+        const uint32_t wps = seg >> 2, i = (uint32_t)w / wps, c = (uint32_t)w - i * wps;
+        return i * (uint32_t)(W * C) + 4u * c;
+    }
     __device__ __forceinline__ bool quads() const { return quads_ok != 0; }
     // quads_ok: the four consecutive vectors n0 .. n0 + 3 (n0 a multiple of 4: four horizontally adjacent blocks)
     // from four 16-byte loads, one per pixel row; w[m] = the four row words of vector n0 + m
@@ -1067,13 +1089,22 @@ __global__ __launch_bounds__(1024) void k_window_sort(const SRC src, int64_t N, 
     __shared__ uint32_t s_cnt[SORT_BUCKETS];
     __shared__ uint32_t s_wsum[T / WAVE];
     __shared__ uint16_t s_inv[SORT_WIN];                    // sorted slot -> position in the window it came from
+    // WORDS with a directly addressable source: where each vector of the window starts (0xffffffff: it needs
+    // padding and goes through src.word) and where its words lie from there -- the copy below then costs a
+    // few instructions per word instead of the index arithmetic of a block lookup
+    __shared__ uint32_t s_base[WORDS ? SORT_WIN : 1];
+    __shared__ uint32_t s_woff[WORDS ? MAX_D_FAST / 4 : 1];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
     const int64_t w0 = (int64_t)blockIdx.x * SORT_WIN;
     const int count = (int)((N - w0) < SORT_WIN ? (N - w0) : SORT_WIN);      // vectors in this window
+    const int dw = d >> 2;
+    const bool direct = WORDS && src.fast_words();
+    const uint8_t *org = src.origin();
     for (int i = tid; i < SORT_BUCKETS; i += T) s_cnt[i] = 0u;
+    if (WORDS && direct)
+        for (int w = tid; w < dw; w += T) s_woff[w] = src.word_off(w);
     __syncthreads();
     uint32_t bucket[PER], rank[PER];
-    const int dw = d >> 2;
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         const int li = j * T + tid;
@@ -1082,7 +1113,19 @@ __global__ __launch_bounds__(1024) void k_window_sort(const SRC src, int64_t N, 
         if (li < count) {
             uint32_t sum = 0;
             if (WORDS) {
-                for (int w = 0; w < dw; ++w) sum = __builtin_amdgcn_sad_u8(src.word(w0 + li, w), 0u, sum);
+                bool inside = false;
+                uint32_t base = 0xffffffffu;
+                if (direct) {
+                    base = src.vec_base(w0 + li, inside);
+                    base = inside ? base : 0xffffffffu;
+                    s_base[li] = base;
+                }
+                if (inside) {
+                    for (int w = 0; w < dw; ++w)
+                        sum = __builtin_amdgcn_sad_u8(*reinterpret_cast<const uint32_t *>(org + base + s_woff[w]), 0u, sum);
+                } else {
+                    for (int w = 0; w < dw; ++w) sum = __builtin_amdgcn_sad_u8(src.word(w0 + li, w), 0u, sum);
+                }
             } else {
                 for (int e = 0; e < d; ++e) sum += src.byte(w0 + li, e);
             }
@@ -1118,9 +1161,20 @@ __global__ __launch_bounds__(1024) void k_window_sort(const SRC src, int64_t N, 
     if (WORDS) {
         uint32_t *out = reinterpret_cast<uint32_t *>(rows) + (size_t)w0 * dw;
         const int total = count * dw;
-        for (int i = tid; i < total; i += T) {
-            const int slot = i / dw, w = i - slot * dw;
-            out[i] = src.word(w0 + (int64_t)s_inv[slot], w);
+        if (direct) {
+            const unsigned long long magic = ((1ull << 32) + (unsigned)dw - 1ull) / (unsigned)dw;   // i / dw for i * dw < 2^32
+            for (int i = tid; i < total; i += T) {
+                const int slot = (int)(((unsigned long long)(unsigned)i * magic) >> 32), w = i - slot * dw;
+                const int li = s_inv[slot];
+                const uint32_t base = s_base[li];
+                out[i] = base != 0xffffffffu ? *reinterpret_cast<const uint32_t *>(org + base + s_woff[w])
+                                             : src.word(w0 + (int64_t)li, w);
+            }
+        } else {
+            for (int i = tid; i < total; i += T) {
+                const int slot = i / dw, w = i - slot * dw;
+                out[i] = src.word(w0 + (int64_t)s_inv[slot], w);
+            }
         }
     } else {
         uint8_t *out = rows + (size_t)w0 * d;
@@ -3409,6 +3463,7 @@ int vq_blocks_sort_img(const uint8_t *img, int H, int W, int C, int bh, int bw, 
     src.nc = (uint32_t)nc; src.seg = (uint32_t)(bw * C); src.d = (uint32_t)d;
     src.words_ok = (((int64_t)W * C) % 4 == 0) && ((reinterpret_cast<uintptr_t>(img) & 3) == 0);
     src.quads_ok = C == 1 && bh == 4 && bw == 4 && H % 4 == 0 && W % 16 == 0 && (reinterpret_cast<uintptr_t>(img) & 15) == 0;
+    src.fast32 = (unsigned long long)H * (unsigned long long)W * (unsigned long long)C < (1ull << 32) ? 1 : 0;
     return run_sort(src, d % 4 == 0, nr * nc, d, sorted, sorted_bytes, static_cast<hipStream_t>(stream));
 }
 
