@@ -1350,7 +1350,7 @@ struct AssignArgs {
 };
 
 // Whether a filter variant settles near-ties inside the kernel (see RESOLVE in k_assign_fast).
-constexpr bool resolves_in_kernel(int dp2, bool lds_cw, bool prune) { return prune && !lds_cw && dp2 <= 16; }
+constexpr bool resolves_in_kernel(int dp2, bool lds_cw, bool prune) { return prune && !lds_cw && dp2 <= 32; }
 
 // Codewords per LDS tile of the LDS_CW variant (about 4 KB of fixed-point rows per tile).
 constexpr int tile_k_for(int dp2) { return dp2 <= 8 ? 128 : (dp2 <= 16 ? 64 : (dp2 <= 32 ? 32 : (dp2 <= 64 ? 16 : 8))); }
