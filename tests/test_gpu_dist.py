@@ -139,3 +139,56 @@ def test_rccl_exchange_world_size_one(tmp_path, oracle):
     for name in ("gather", "allreduce"):
         assert np.array_equal(r[name + "_cb"], ref["codebook"])
         assert np.array_equal(r[name + "_dist"], ref["distortions"])
+
+
+def _batch_images(n_images=16, side=512):
+    """A batch of grayscale images (config 4 of the baseline in miniature: many images, one codebook)."""
+    rng = np.random.default_rng(404)
+    yy, xx = np.mgrid[0:side, 0:side]
+    imgs = []
+    for i in range(n_images):
+        base = 96 + 64 * np.sin(xx / (9.0 + i)) * np.cos(yy / (13.0 + 2 * i)) + rng.normal(0, 6, (side, side))
+        imgs.append(np.clip(base + 8 * i, 0, 255).astype(np.uint8))
+    return imgs
+
+
+def _batch_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vector_quantization_amd import HipEngine, train_lbg
+        eng = HipEngine("cuda:0")
+        imgs = _batch_images()
+        mine = imgs[rank * len(imgs) // world:(rank + 1) * len(imgs) // world]       # the batch is sharded by image
+        dev = [torch.from_numpy(im).to("cuda:0") for im in mine]
+        blocks = torch.cat([eng.blocks_from_image(im, 4, 4) for im in dev])
+        res = train_lbg(eng, blocks, 64, group=dist.group.WORLD, log=None)
+        labels = [eng.encode_image(im, 4, 4, res.codebook).cpu().numpy() for im in dev]
+        np.savez(os.path.join(out_dir, f"batch{rank}.npz"), codebook=res.codebook.cpu().numpy(),
+                 dist=np.array(res.distortions), labels=np.stack(labels))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_batch_of_images_sharded_over_two_ranks(tmp_path):
+    """Images of a batch go to different ranks, the codebook is trained over all of them: codebook, every
+    distortion and every image's labels equal the single-process run on the whole batch."""
+    from vector_quantization_amd import HipEngine, train_lbg
+    eng = HipEngine("cuda:0")
+    imgs = _batch_images()
+    dev = [torch.from_numpy(im).to("cuda:0") for im in imgs]
+    blocks = torch.cat([eng.blocks_from_image(im, 4, 4) for im in dev])
+    single = train_lbg(eng, blocks, 64, log=None)
+    want = np.stack([eng.encode_image(im, 4, 4, single.codebook).cpu().numpy() for im in dev])
+    mp.spawn(_batch_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "batch0.npz"), np.load(tmp_path / "batch1.npz")
+    assert np.array_equal(r0["codebook"], single.codebook.cpu().numpy())
+    assert np.array_equal(r1["codebook"], r0["codebook"])
+    assert np.array_equal(r0["dist"], np.array(single.distortions))          # 16384 vectors per image: aligned shards
+    assert np.array_equal(np.concatenate([r0["labels"], r1["labels"]]), want)
+    # decoded images of the batch through the plain and the sharded labels are the same pixels
+    dec = eng.decode(torch.from_numpy(want[3]).to("cuda:0").view(128, 128), single.codebook, 4, 4, 1).cpu().numpy()
+    dec2 = eng.decode(torch.from_numpy(r0["labels"][3]).to("cuda:0").view(128, 128), single.codebook, 4, 4, 1).cpu().numpy()
+    assert np.array_equal(dec, dec2)
