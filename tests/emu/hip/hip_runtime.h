@@ -41,21 +41,32 @@ constexpr int WAVE = 64;
 constexpr size_t LDS_BYTES = 160 * 1024;
 
 struct Barrier {                       // reusable; threads that finish early leave with drop()
+    // the bookkeeping sits under a mutex; waiters spin on the generation counter and yield (hundreds of
+    // threads share a few cores: a condition variable's wake-ups cost far more than the yields)
     std::mutex m;
-    std::condition_variable cv;
     int count = 0, waiting = 0;
-    uint64_t gen = 0;
+    std::atomic<uint64_t> gen{0};
     void init(int n) { count = n; waiting = 0; }
     void wait() {
-        std::unique_lock<std::mutex> l(m);
-        const uint64_t g = gen;
-        if (++waiting == count) { waiting = 0; ++gen; cv.notify_all(); }
-        else cv.wait(l, [&] { return gen != g; });
+        uint64_t g;
+        {
+            std::lock_guard<std::mutex> l(m);
+            g = gen.load(std::memory_order_relaxed);
+            if (++waiting == count) {
+                waiting = 0;
+                gen.store(g + 1, std::memory_order_release);
+                return;
+            }
+        }
+        while (gen.load(std::memory_order_acquire) == g) std::this_thread::yield();
     }
     void drop() {
-        std::unique_lock<std::mutex> l(m);
+        std::lock_guard<std::mutex> l(m);
         --count;
-        if (count > 0 && waiting == count) { waiting = 0; ++gen; cv.notify_all(); }
+        if (count > 0 && waiting == count) {
+            waiting = 0;
+            gen.store(gen.load(std::memory_order_relaxed) + 1, std::memory_order_release);
+        }
     }
 };
 struct WaveState { Barrier bar; uint64_t x[WAVE]; };
@@ -103,19 +114,28 @@ template <class F> void launch(dim3 grid, dim3 block, size_t lds, F body) {
         fprintf(stderr, "emu: launch shape not modelled (block %u, lds %zu)\n", block.x, lds);
         abort();
     }
-    for (unsigned bz = 0; bz < grid.z; ++bz)
-        for (unsigned by = 0; by < grid.y; ++by)
-            for (unsigned bx = 0; bx < grid.x; ++bx) {
-                Block blk;
-                blk.bar.init((int)block.x);
-                blk.waves = std::vector<WaveState>(block.x / WAVE);
-                for (auto &w : blk.waves) w.bar.init(WAVE);
-                g_block = &blk;
-                memset(g_lds, 0xCD, LDS_BYTES);                // LDS comes up with garbage, as on the GPU
-                std::vector<std::thread> th;
-                th.reserve(block.x);
-                for (unsigned t = 0; t < block.x; ++t)
-                    th.emplace_back([&, t] {
+    // block.x OS threads serve all workgroups of the launch, one workgroup after another: before each one,
+    // thread 0 re-arms the workgroup's barriers and fills the LDS with garbage (as on the GPU, it comes up
+    // undefined); `outer` keeps the threads together between workgroups
+    const unsigned nthreads = block.x;
+    Block blk;
+    blk.waves = std::vector<WaveState>(nthreads / WAVE);
+    Barrier outer;
+    outer.init((int)nthreads);
+    g_block = &blk;
+    std::vector<std::thread> th;
+    th.reserve(nthreads);
+    for (unsigned t = 0; t < nthreads; ++t)
+        th.emplace_back([&, t] {
+            for (unsigned bz = 0; bz < grid.z; ++bz)
+                for (unsigned by = 0; by < grid.y; ++by)
+                    for (unsigned bx = 0; bx < grid.x; ++bx) {
+                        if (t == 0) {
+                            blk.bar.init((int)nthreads);
+                            for (auto &w : blk.waves) w.bar.init(WAVE);
+                            memset(g_lds, 0xCD, LDS_BYTES);
+                        }
+                        outer.wait();
                         threadIdx = Idx{t, 0, 0};
                         blockIdx = Idx{bx, by, bz};
                         blockDim = Idx{block.x, 1, 1};
@@ -123,10 +143,11 @@ template <class F> void launch(dim3 grid, dim3 block, size_t lds, F body) {
                         body();
                         blk.waves[t / WAVE].bar.drop();
                         blk.bar.drop();
-                    });
-                for (auto &t : th) t.join();
-                g_block = nullptr;
-            }
+                        outer.wait();
+                    }
+        });
+    for (auto &t : th) t.join();
+    g_block = nullptr;
 }
 }  // namespace emu
 

@@ -141,6 +141,7 @@ struct WsLayout {
     size_t bias;       // Kpad uint32: key bias (original row index, plus the never-wins bit for duplicate rows)
     size_t c16u;       // K * dp2 uint32: the same rows in original order (scratch of the prepare kernel)
     size_t postab;     // POSTAB_WORDS uint32: sum threshold -> position in the sorted codebook
+    size_t prep_tmp;   // scratch of the prepare kernels: K uint64 row hashes, K uint32 element sums, K uint32 sorted sums
     size_t acc_rep;    // NREP * K * (d + 1) uint64: replicas of the [sums | count] table (fused accumulation)
     size_t cbT;        // d * K doubles: transposed fp64 codebook, columns in the order of the c16 rows
     size_t cb_u8;      // K * d bytes: codebook truncated to uint8 (decode)
@@ -163,6 +164,7 @@ WsLayout ws_layout(int K, int d, int64_t N) {
     L.bias = off;     off += align_up(kpad * 4, 256);
     L.c16u = off;     off += align_up((size_t)K * dp2 * 4, 256);
     L.postab = off;   off += align_up((size_t)POSTAB_WORDS * 4, 256);
+    L.prep_tmp = off; off += align_up((size_t)K * 16, 256);
     L.acc_rep = off;  off += (size_t)K * (d + 1) * 4 <= 40 * 1024 ? align_up((size_t)NREP * K * (d + 1) * 8, 256) : 0;
     L.cbT = off;      off += align_up((size_t)K * d * 8, 256);
     L.cb_u8 = off;    off += align_up((size_t)K * d, 256);
@@ -576,177 +578,186 @@ __device__ __forceinline__ uint32_t prep_ceil_sat(double c) {       // ceil, sat
     return (uint32_t)ceil(c);
 }
 
-// Dynamic LDS: an open-addressing table of 2*K slots (keys = 64-bit row hashes), the K row hashes,
-// then per slot the smallest row index seen for its key.
-__global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb, int K, int d, int dp2, uint32_t clim,
-                                                  PrepHeader *__restrict__ hdr, uint32_t *__restrict__ c16,
-                                                  uint32_t *__restrict__ bias, double *__restrict__ cbT,
-                                                  uint32_t *__restrict__ c16u, uint32_t *__restrict__ postab) {
-    extern __shared__ __align__(16) unsigned long long s_keys[];
-    __shared__ uint32_t s_cmax;
-    __shared__ uint32_t s_emax;
-    __shared__ __align__(16) uint32_t s_sc[PREP_SORT_CAP + 4];   // element sum of each fixed-point row, original order
-    // the same sums in ascending order: written after the duplicate scan is over, into the space of its hash
-    // table (K <= PREP_SORT_CAP codebooks get at least K * 4 bytes of dynamic LDS)
-    uint32_t *s_scs = reinterpret_cast<uint32_t *>(s_keys);
-    const bool do_sort = K <= PREP_SORT_CAP;
-    uint32_t *crow_out = do_sort ? c16u : c16;       // unsorted rows go to scratch first when sorting
-    const bool scan_dups = K <= PREP_HASH_CAP && K > 1;
-    const uint32_t T = scan_dups ? 2u * (uint32_t)K : 0u;       // table slots
-    unsigned long long *s_rowhash = s_keys + T;                  // K entries
-    uint32_t *s_first = reinterpret_cast<uint32_t *>(s_rowhash + (scan_dups ? K : 0));
-    if (threadIdx.x == 0) {
-        s_cmax = 0;
-        s_emax = 0;
-    }
-    if (threadIdx.x < 4 && do_sort) s_sc[K + threadIdx.x] = 0xffffffffu;
-    for (uint32_t i = threadIdx.x; i < T; i += blockDim.x) {
-        s_keys[i] = 0ull;
-        s_first[i] = 0xffffffffu;
-    }
-    __syncthreads();
-    // phase A: largest entry
-    const int64_t n = (int64_t)K * d;
+// ---- codebook preparation across the chip (any K, any d <= 192) ------------------------------------------
+// Four launches: k_prep_max (largest entry -> the fixed-point scale), k_prep_rows (one wave per codeword:
+// fixed-point row, rounding-error bound, element sum, row hash), k_prep_rank (codebooks up to PREP_SORT_CAP
+// rows: position in ascending (element sum, index) order by counting, duplicate rows, rows and transposed
+// fp64 copy moved to their sorted place), k_prep_finish (position table, pad rows, header).  The header's
+// cmax and emax are zeroed before the first launch and filled with atomic maxima.
+__global__ __launch_bounds__(256) void k_prep_max(const double *__restrict__ cb, int64_t n, PrepHeader *hdr) {
     uint32_t lmax = 0;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const uint32_t m = prep_ceil_sat(cb[i]);
         lmax = m > lmax ? m : lmax;
     }
-    atomicMax(&s_cmax, lmax);
-    __syncthreads();
-    const uint32_t cmax = s_cmax;
-    // largest scale 2^s (s <= 8) that keeps both the pixels (<= 255) and the largest codebook entry
-    // within clim, the fixed-point limit the key layout allows
+    lmax = wave_reduce_u32<true>(lmax);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && lmax) atomicMax(&hdr->cmax, lmax);
+}
+
+// largest scale 2^s (s <= 8) that keeps both the pixels (<= 255) and the largest codebook entry within clim,
+// the fixed-point limit the key layout allows
+__device__ __forceinline__ int prep_shift(uint32_t cmax, uint32_t clim) {
     const uint64_t top = cmax > 255u ? cmax : 255u;
     int s = 8;
     while (s > 0 && (top << s) > (uint64_t)clim) --s;
+    return s;
+}
+
+// rows_out: c16u (original order, moved by k_prep_rank) for codebooks that get sorted, else c16 itself; in that
+// case the transposed copy and the biases are written here too.
+__global__ __launch_bounds__(256) void k_prep_rows(const double *__restrict__ cb, int K, int d, int dp2, uint32_t clim,
+                                                   PrepHeader *hdr, uint32_t *__restrict__ rows_out,
+                                                   uint32_t *__restrict__ sc, unsigned long long *__restrict__ hash,
+                                                   double *__restrict__ cbT_plain, uint32_t *__restrict__ bias_plain) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int s = prep_shift(hdr->cmax, clim);
     const double scale = (double)(1u << s);
     const double qmax = (double)clim;
-    // phase B: one thread per codeword: fixed-point row, rounding-error bound, transposed copy, row
-    // hash.  The row is read eight entries at a time (loads first, arithmetic after).
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    const int nwaves = gridDim.x * 4;
+    for (int k = blockIdx.x * 4 + (threadIdx.x >> 6); k < K; k += nwaves) {        // (wave-uniform)
         const double *row = cb + (size_t)k * d;
         double err = 0.0;
-        uint32_t sc = 0;
-        unsigned long long h = 0x243F6A8885A308D3ull;
-        {
-            for (int p0 = 0; p0 < dp2; p0 += 4) {
-                double c[8];
+        uint32_t scv = 0;
+        unsigned long long h = 0;
+        for (int e0 = 0; e0 < 2 * dp2; e0 += WAVE) {
+            const int e = e0 + lane;
+            uint32_t q = 0;
+            if (e < d) {
+                const double cv = row[e];
+                const double t = cv * scale;
+                double qd = rint(t);
+                if (!(qd >= 0.0)) qd = 0.0;          // also catches NaN
+                if (qd > qmax) qd = qmax;
+                double de = fabs(t - qd);
+                if (!(de == de)) de = 4.0e9;
+                err += de;
+                q = (uint32_t)qd;
+                scv += q;
+                h += mix64(0x243F6A8885A308D3ull + (unsigned long long)e, (unsigned long long)__double_as_longlong(cv));
+                if (cbT_plain) cbT_plain[(size_t)e * K + k] = cv;
+            }
+            const uint32_t qn = __shfl_xor(q, 1, WAVE);                              // the odd neighbour's entry
+            if (!(lane & 1) && e < 2 * dp2) rows_out[(size_t)k * dp2 + (e >> 1)] = q | (qn << 16);
+        }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int e = 2 * p0 + j;
-                    c[j] = row[e < d ? e : d - 1];
-                }
+        for (int off = 1; off < WAVE; off <<= 1) {                                  // the same value in every lane
+            err += __shfl_xor(err, off, WAVE);
+            scv += __shfl_xor(scv, off, WAVE);
+            h += __shfl_xor(h, off, WAVE);
+        }
+        if (lane == 0) {
+            h = mix64(h, 0x9E3779B97F4A7C15ull);
+            sc[k] = scv;
+            hash[k] = h;
+            // strict integer upper bound of err (plus slack for the fp64 rounding of err itself)
+            const uint32_t ek = (err < 2.0e9) ? (uint32_t)err + 2u : 0x7fffffffu;
+            atomicMax(&hdr->emax, ek);
+            if (bias_plain) bias_plain[k] = (uint32_t)k;
+        }
+    }
+}
+
+// Dynamic LDS: K element sums (uint32, padded to a multiple of 4), then K row hashes (uint64).  A workgroup
+// takes PREP_RANK_ROWS codewords, 16 threads each: they split the scan that ranks the codeword and looks for the
+// first earlier row with its sum and hash (verified bit by bit: identical rows give identical distances, so
+// the later one can never win -- ties go to the lower index -- and gets the never-competes bit; a missed
+// duplicate only costs re-checks); then each wave moves four of the rows.
+constexpr int PREP_RANK_ROWS = 16;
+__global__ __launch_bounds__(256) void k_prep_rank(const double *__restrict__ cb, int K, int d, int dp2,
+                                                   const uint32_t *__restrict__ sc, const unsigned long long *__restrict__ hash,
+                                                   const uint32_t *__restrict__ c16u, uint32_t *__restrict__ c16,
+                                                   uint32_t *__restrict__ bias, double *__restrict__ cbT,
+                                                   uint32_t *__restrict__ scs) {
+    extern __shared__ __align__(16) unsigned long long s_prep[];
+    __shared__ uint32_t s_pos[PREP_RANK_ROWS];
+    const int kq = (K + 3) & ~3;
+    uint32_t *s_sc = reinterpret_cast<uint32_t *>(s_prep);                      // K sums, padded to a multiple of 4
+    unsigned long long *s_h = s_prep + kq / 2;                                  // K hashes
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    for (int i = tid; i < kq; i += 256) s_sc[i] = i < K ? sc[i] : 0xffffffffu;
+    for (int i = tid; i < K; i += 256) s_h[i] = hash[i];
+    __syncthreads();
+    const int r = tid >> 4, sub = tid & 15;
+    const int k = blockIdx.x * PREP_RANK_ROWS + r;
+    const bool live = k < K;
+    const int kc = live ? k : K - 1;
+    const uint32_t me = s_sc[kc];
+    const unsigned long long mh = s_h[kc];
+    uint32_t pos = 0;
+    int first = kc;
+    {
+        const uint4 *sv = reinterpret_cast<const uint4 *>(s_sc);
+#pragma unroll 4
+        for (int j4 = sub; j4 < kq / 4; j4 += 16) {
+            const uint4 o = sv[j4];
+            const int j = 4 * j4;
+            pos += (o.x < me || (o.x == me && j < kc)) ? 1u : 0u;
+            pos += (o.y < me || (o.y == me && j + 1 < kc)) ? 1u : 0u;
+            pos += (o.z < me || (o.z == me && j + 2 < kc)) ? 1u : 0u;
+            pos += (o.w < me || (o.w == me && j + 3 < kc)) ? 1u : 0u;
+            if (o.x == me || o.y == me || o.z == me || o.w == me) {             // rare: look at the hashes
+                const uint32_t ov[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
-                for (int pp = 0; pp < 4; ++pp) {
-                    const int p = p0 + pp;
-                    if (p < dp2) {
-                        uint32_t pair = 0;
-#pragma unroll
-                        for (int hh = 0; hh < 2; ++hh) {
-                            const int e = 2 * p + hh;
-                            if (e < d) {
-                                prep_quant(c[2 * pp + hh], hh, scale, qmax, pair, err, sc, h);
-                                if (!do_sort) cbT[(size_t)e * K + k] = c[2 * pp + hh];   // sorted codebooks: written in phase D
-                            }
-                        }
-                        crow_out[(size_t)k * dp2 + p] = pair;
-                    }
-                }
+                for (int t = 0; t < 4; ++t)
+                    if (ov[t] == me && j + t < first && s_h[j + t] == mh) first = j + t;
             }
         }
-        if (do_sort) s_sc[k] = sc;
-        // strict integer upper bound of err (plus slack for the fp64 rounding of err itself)
-        uint32_t ek = (err < 2.0e9) ? (uint32_t)err + 2u : 0x7fffffffu;
-        atomicMax(&s_emax, ek);
-        // record the smallest index of each distinct row hash (0 marks an empty slot)
-        if (scan_dups) {
-            if (h == 0ull) h = 1ull;
-            s_rowhash[k] = h;
-            uint32_t slot = (uint32_t)(h % T);
-            for (uint32_t probe = 0; probe < T; ++probe) {
-                unsigned long long old = atomicCAS(&s_keys[slot], 0ull, h);
-                if (old == 0ull || old == h) {
-                    atomicMin(&s_first[slot], (uint32_t)k);
-                    break;
-                }
-                slot = slot + 1 == T ? 0 : slot + 1;
-            }
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+            pos += __shfl_xor(pos, m, WAVE);
+            const int of = __shfl_xor(first, m, WAVE);
+            first = of < first ? of : first;
         }
+    }
+    if (live && sub == 0) {
+        uint32_t dup = 0;
+        if (first < k) {
+            const unsigned long long *rowb = reinterpret_cast<const unsigned long long *>(cb + (size_t)k * d);
+            const unsigned long long *rj = reinterpret_cast<const unsigned long long *>(cb + (size_t)first * d);
+            int e = 0;
+            while (e < d && rj[e] == rowb[e]) ++e;
+            if (e == d) dup = 1u;
+        }
+        scs[pos] = me;
+        bias[pos] = (uint32_t)k | (dup << 31);
+        s_pos[r] = pos;
     }
     __syncthreads();
-    // phase C: row k is a duplicate when the first row with its hash is an earlier, bit-identical
-    // row.  Identical rows give identical distances, so the later one can never win (ties go to the
-    // lower index) and gets the never-competes bit.  A missed duplicate only costs re-checks.
-    uint32_t dupmask = 0;                                        // bit i: this thread's i-th row is a duplicate
-    if (scan_dups) {
-        int it = 0;
-        for (int k = threadIdx.x; k < K; k += blockDim.x, ++it) {
-            const double *row = cb + (size_t)k * d;
-            const unsigned long long h = s_rowhash[k];
-            uint32_t slot = (uint32_t)(h % T);
-            uint32_t first = 0xffffffffu;
-            for (uint32_t probe = 0; probe < T; ++probe) {
-                unsigned long long key = s_keys[slot];
-                if (key == h) {
-                    first = s_first[slot];
-                    break;
-                }
-                if (key == 0ull) break;
-                slot = slot + 1 == T ? 0 : slot + 1;
-            }
-            if (first < (uint32_t)k) {
-                const unsigned long long *rowb = reinterpret_cast<const unsigned long long *>(row);
-                const unsigned long long *rj = reinterpret_cast<const unsigned long long *>(cb + (size_t)first * d);
-                int e = 0;
-                while (e < d && rj[e] == rowb[e]) ++e;
-                if (e == d) dupmask |= 1u << it;
-            }
+    // the fixed-point rows and the transposed fp64 copy go to their sorted place: c16[pos], cbT[e][pos]
+    const int wv = tid >> 6;
+#pragma unroll
+    for (int t = 0; t < PREP_RANK_ROWS / 4; ++t) {
+        const int rr = wv * (PREP_RANK_ROWS / 4) + t;
+        const int k2 = blockIdx.x * PREP_RANK_ROWS + rr;
+        if (k2 < K) {                                                           // (wave-uniform)
+            const uint32_t p2 = s_pos[rr];
+            for (int p = lane; p < dp2; p += WAVE) c16[(size_t)p2 * dp2 + p] = c16u[(size_t)k2 * dp2 + p];
+            for (int e = lane; e < d; e += WAVE) cbT[(size_t)e * K + p2] = cb[(size_t)k2 * d + e];
         }
     }
-    __syncthreads();                                             // the hash table is free: s_scs may be written
-    // phase D: position of the row in ascending (element sum, index) order, by counting
-    {
-        int it = 0;
-        for (int k = threadIdx.x; k < K; k += blockDim.x, ++it) {
-            const uint32_t dup = scan_dups ? (dupmask >> it) & 1u : 0u;
-            uint32_t pos = (uint32_t)k;
-            if (do_sort) {
-                const uint32_t me = s_sc[k];
-                pos = 0;
-                // four sums per LDS read (entries K .. K + 3 hold 0xffffffff, which never counts)
-                const uint4 *sv = reinterpret_cast<const uint4 *>(s_sc);
-#pragma unroll 4
-                for (int j4 = 0; j4 < (K + 3) / 4; ++j4) {
-                    const uint4 o = sv[j4];
-                    const int j = 4 * j4;
-                    pos += (o.x < me || (o.x == me && j < k)) ? 1u : 0u;
-                    pos += (o.y < me || (o.y == me && j + 1 < k)) ? 1u : 0u;
-                    pos += (o.z < me || (o.z == me && j + 2 < k)) ? 1u : 0u;
-                    pos += (o.w < me || (o.w == me && j + 3 < k)) ? 1u : 0u;
-                }
-                s_scs[pos] = me;
-                // the fixed-point row and the transposed fp64 copy go to their sorted place: c16[pos], cbT[e][pos]
-                {
-                    for (int p = 0; p < dp2; ++p) c16[(size_t)pos * dp2 + p] = c16u[(size_t)k * dp2 + p];
-                    for (int e = 0; e < d; ++e) cbT[(size_t)e * K + pos] = cb[(size_t)k * d + e];
-                }
-            }
-            bias[pos] = (uint32_t)k | (dup << 31);
-        }
-    }
+}
+
+// One workgroup: position table over the sums a vector can have (sorted codebooks), pad rows, header.
+__global__ __launch_bounds__(1024) void k_prep_finish(int K, int d, int dp2, uint32_t clim, int do_sort, PrepHeader *hdr,
+                                                      const uint32_t *__restrict__ scs, uint32_t *__restrict__ c16,
+                                                      uint32_t *__restrict__ bias, uint32_t *__restrict__ postab) {
+    __shared__ uint32_t s_scs[PREP_SORT_CAP];
+    const int tid = threadIdx.x;
+    const int s = prep_shift(hdr->cmax, clim);
+    if (do_sort)
+        for (int i = tid; i < K; i += 1024) s_scs[i] = scs[i];
     // pad rows: zeros with the never-competes bias, so that batches of codewords may run past K
     const int kpad = (K + 7) / 8 * 8;
-    for (int i = threadIdx.x; i < (kpad - K) * dp2; i += blockDim.x) c16[(size_t)K * dp2 + i] = 0u;
-    for (int i = K + threadIdx.x; i < kpad; i += blockDim.x) bias[i] = 0x80000000u;
+    for (int i = tid; i < (kpad - K) * dp2; i += 1024) c16[(size_t)K * dp2 + i] = 0u;
+    for (int i = K + tid; i < kpad; i += 1024) bias[i] = 0x80000000u;
     // position table over the sums a vector can have: 0 .. d * 255 << s
     const uint32_t mtab = (uint32_t)d * (255u << s) + 1u;
     uint32_t tshift = 0;
     while ((mtab >> tshift) > (uint32_t)POSTAB_NT - 1u) ++tshift;
     const uint32_t nt = (mtab >> tshift) + 1u;                 // entries 0 .. nt cover every vector sum
+    __syncthreads();
     if (do_sort) {
-        __syncthreads();
-        for (uint32_t t = threadIdx.x; t <= nt + 1u; t += blockDim.x) {
+        for (uint32_t t = tid; t <= nt + 1u; t += 1024) {
             uint32_t lo = 0, hi = (uint32_t)K;                 // lower bound of (t << tshift) in s_scs
             const uint64_t target = (uint64_t)t << tshift;
             while (lo < hi) {
@@ -756,10 +767,8 @@ __global__ __launch_bounds__(1024) void k_prepare(const double *__restrict__ cb,
             postab[t] = t == nt + 1u ? (uint32_t)K : lo;
         }
     }
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         hdr->shift = (uint32_t)s;
-        hdr->emax = s_emax;
-        hdr->cmax = cmax;
         hdr->sorted = do_sort ? 1u : 0u;
         hdr->tshift = tshift;
         hdr->nt = nt;
@@ -2949,27 +2958,40 @@ int run_prepare(const double *cb, int K, int d, void *ws, hipStream_t st) {
     uint32_t *c16 = reinterpret_cast<uint32_t *>(w + L.c16), *bias = reinterpret_cast<uint32_t *>(w + L.bias);
     double *cbT = reinterpret_cast<double *>(w + L.cbT);
     uint32_t *postab = reinterpret_cast<uint32_t *>(w + L.postab);
-    if (d <= 16 && K <= 1024) {                             // short rows, small codebooks: 4, 2 or 1 threads per codeword
-        const uint32_t clim = key_layout(K, dp2).clim;
+    const uint32_t clim = key_layout(K, dp2).clim;
+    if (d <= 16 && K <= 512) {                              // short rows, small codebooks: one workgroup, one launch
         if (K <= 256)
             hipLaunchKernelGGL(k_prepare_small<4>, dim3(1), dim3(1024), hash_lds, st, cb, K, d, dp2, clim, hdr, c16, bias, cbT, postab);
-        else if (K <= 512)
-            hipLaunchKernelGGL(k_prepare_small<2>, dim3(1), dim3(1024), hash_lds, st, cb, K, d, dp2, clim, hdr, c16, bias, cbT, postab);
         else
-            hipLaunchKernelGGL(k_prepare_small<1>, dim3(1), dim3(1024), hash_lds, st, cb, K, d, dp2, clim, hdr, c16, bias, cbT, postab);
+            hipLaunchKernelGGL(k_prepare_small<2>, dim3(1), dim3(1024), hash_lds, st, cb, K, d, dp2, clim, hdr, c16, bias, cbT, postab);
         LAUNCH_CHECK("k_prepare_small");
         return VQ_OK;
     }
-    auto kern = k_prepare;
-    if (hash_lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)hash_lds));
-    hipLaunchKernelGGL(kern, dim3(1), dim3(1024), hash_lds, st, cb, K, d, dp2, key_layout(K, dp2).clim,
-                       reinterpret_cast<PrepHeader *>(w + L.header),
-                       reinterpret_cast<uint32_t *>(w + L.c16), reinterpret_cast<uint32_t *>(w + L.bias),
-                       reinterpret_cast<double *>(w + L.cbT), reinterpret_cast<uint32_t *>(w + L.c16u),
-                       reinterpret_cast<uint32_t *>(w + L.postab));
-    LAUNCH_CHECK("k_prepare");
+    DeviceInfo di;
+    int rc = device_info(di);
+    if (rc) return rc;
+    const bool do_sort = K <= PREP_SORT_CAP;
+    uint32_t *c16u = reinterpret_cast<uint32_t *>(w + L.c16u);
+    unsigned long long *hash = reinterpret_cast<unsigned long long *>(w + L.prep_tmp);
+    uint32_t *sc = reinterpret_cast<uint32_t *>(hash + K), *scs = sc + K;
+    HIP_TRY(hipMemsetAsync(hdr, 0, sizeof(PrepHeader), st));
+    const int64_t n = (int64_t)K * d;
+    hipLaunchKernelGGL(k_prep_max, dim3(grid_for(n, 256 * 8, di.cus * 4)), dim3(256), 0, st, cb, n, hdr);
+    LAUNCH_CHECK("k_prep_max");
+    hipLaunchKernelGGL(k_prep_rows, dim3(grid_for(K, 4, di.cus * 8)), dim3(256), 0, st, cb, K, d, dp2, clim, hdr,
+                       do_sort ? c16u : c16, sc, hash, do_sort ? nullptr : cbT, do_sort ? nullptr : bias);
+    LAUNCH_CHECK("k_prep_rows");
+    if (do_sort) {
+        const size_t lds = (size_t)K * 8 + (size_t)((K + 3) & ~3) * 4;
+        if (lds > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_prep_rank), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds));
+        hipLaunchKernelGGL(k_prep_rank, dim3((K + PREP_RANK_ROWS - 1) / PREP_RANK_ROWS), dim3(256), lds, st, cb, K, d, dp2, sc,
+                           hash, c16u, c16, bias, cbT, scs);
+        LAUNCH_CHECK("k_prep_rank");
+    }
+    hipLaunchKernelGGL(k_prep_finish, dim3(1), dim3(1024), 0, st, K, d, dp2, clim, do_sort ? 1 : 0, hdr, scs, c16, bias, postab);
+    LAUNCH_CHECK("k_prep_finish");
     return VQ_OK;
 }
 
