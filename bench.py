@@ -137,6 +137,11 @@ def event_ms(fn, reps, device):
     return float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
 
+def _nbytes_sorted(eng, d, N):
+    from vector_quantization_amd import _lib
+    return _lib.lib.vq_sorted_bytes(int(d), int(N))
+
+
 def search_profile(eng, img, bh, bw, cb, reps, device):
     """Timings and statistics of the search on one (image, codebook): the filter kernel alone (HIP events on
     its stream), the fix-up alone, the evaluated share of all (vector, codeword) pairs."""
@@ -160,12 +165,18 @@ def search_profile(eng, img, bh, bw, cb, reps, device):
     in_filter = bool(pruned and eng.prune_resolves_in_filter(K, d))     # near-ties settled inside the filter kernel
     fixup_ms = 0.0 if in_filter else event_ms(lambda: eng.encode_prepared(blocks, prepared, phases=2, **kw), reps, device)
     both_ms = event_ms(lambda: eng.encode_prepared(blocks, prepared, **kw), reps, device)
+    sort_ms = event_ms(lambda: eng.sort_image(img, bh, bw, out=srt if pruned else None), reps, device) if pruned else None
+    prep_ms = event_ms(lambda: eng.prepare_codebook(cb, 0), reps, device)
+    e2e_scratch = torch.empty(max(int(_nbytes_sorted(eng, d, N)), N * d, 16), dtype=torch.uint8, device=device)
+    e2e_ms = event_ms(lambda: eng.encode_image(img, bh, bw, cb, scratch=e2e_scratch, labels=labels), reps, device)
     pairs_all = float(N) * K
     pairs_eval = float(pairs_eval)
     ops_exec = 2.0 * d * pairs_eval
     out = dict(K=K, d=d, N=N, pruned_search=bool(pruned), near_ties_settled_in_filter=in_filter,
                filter_kernel_ms=filter_ms, fixup_kernel_ms=fixup_ms,
-               search_ms=both_ms, vectors_per_s=N / (both_ms * 1e-3), queued_for_fp64_frac=queued / N,
+               search_ms=both_ms, vectors_per_s=N / (both_ms * 1e-3), image_sort_ms=sort_ms, codebook_prepare_ms=prep_ms,
+               image_to_labels_ms=e2e_ms, image_to_labels_vectors_per_s=N / (e2e_ms * 1e-3),
+               queued_for_fp64_frac=queued / N,
                evaluated_pair_frac=pairs_eval / pairs_all,
                executed_tops=ops_exec / (filter_ms * 1e-3) / 1e12,
                frac_of_sad_ceiling=ops_exec / (filter_ms * 1e-3) / 1e12 / PEAK_SAD_TOPS,
@@ -275,13 +286,11 @@ def main():
         else:
             pmc_note = "HBM traffic per launch from profiles/r02_pmc_*.csv (rocprofv3 --pmc passes of this library build)"
 
-    def pmc_bytes(prefix):
-        if not pmc:
-            return None
-        v = [b for k, b in pmc["hbm_bytes_by_kernel"].items() if k.startswith(prefix)]
-        return float(sum(v)) if v else None
+    def pmc_bytes(role):
+        r = (pmc or {}).get("roles", {}).get(role)
+        return float(r["hbm_bytes"]) if r else None
 
-    traffic = pmc_bytes("k_assign_fast")
+    traffic = pmc_bytes("search_filter")
     roofline = dict(
         bound="valu", unit="TFLOP/s",
         kernel="k_assign_fast<DP2=8, R=4, packed keys, scalar-load codewords, PRUNE> (the filter launch of "
@@ -314,12 +323,12 @@ def main():
     hbm_kernels = {
         "image_sort": dict(bound="hbm", kernel="k_window_sort_lds<4, image source> (vq_blocks_sort_img)", kernel_ms=sort_ms,
                            achieved=sort_alg / (sort_ms * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
-                           frac=sort_alg / (sort_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, traffic=pmc_bytes("k_window_sort"),
+                           frac=sort_alg / (sort_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, traffic=pmc_bytes("image_sort"),
                            algorithmic_bytes_per_vector=2 * d + 2,
                            note="reads every pixel once, writes every row once at its sorted place plus a 2-byte origin"),
         "decode": dict(bound="hbm", kernel="k_decode_quads (vq_decode_u8)", kernel_ms=dec_ms,
                        achieved=dec_alg / (dec_ms * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
-                       frac=dec_alg / (dec_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, traffic=pmc_bytes("k_decode"),
+                       frac=dec_alg / (dec_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, traffic=pmc_bytes("decode"),
                        algorithmic_bytes_per_vector=d + 4),
         "codebook_prepare": dict(kernel="k_prepare", kernel_ms=prep_ms, note="K*d entries; latency-bound"),
     }

@@ -83,13 +83,39 @@ json.dump(per_kernel, open(os.path.join(out, f"{tag}_pmc_per_kernel.json"), "w")
 
 N = 2048 * 2048
 big = [e for e in per_kernel if "hbm_read_bytes" in e]
+
+
+def grid_of(key):
+    return int(key.split("[grid=")[1].rstrip("]") or 0)
+
+
+def full_size(key):                      # the launches over all 4 194 304 vectors of the workload
+    return grid_of(key) >= 262144
+
+
+def role_bytes(pred):
+    c = [e for e in big if pred(e["kernel"]) and full_size(e["kernel"])]
+    if not c:
+        return None
+    e = max(c, key=lambda e: grid_of(e["kernel"]))
+    return dict(kernel=e["kernel"], hbm_bytes=e["hbm_read_bytes"] + e["hbm_write_bytes"])
+
+
+roles = dict(
+    search_filter=role_bytes(lambda k: k.startswith("k_assign_fast") and k.split("[")[0].endswith("false, true, false>")),
+    search_full=role_bytes(lambda k: k.startswith("k_assign_fast") and k.split("[")[0].endswith("false, false, false>")),
+    lbg_assign=role_bytes(lambda k: k.startswith("k_assign_fast") and k.split("[")[0].endswith("false, true, true>")),
+    image_sort=role_bytes(lambda k: k.startswith("k_window_sort") and "SrcImage" in k),
+    decode=role_bytes(lambda k: k.startswith("k_decode")),
+    blocks=role_bytes(lambda k: k.startswith("k_blocks")))
 summary = dict(
+    roles=roles,
     library_sha256_16=lib_sha,
     workload="tools/prof_encode.py: 8192x8192 gray, 4x4 blocks, K=256 (N = 4194304 block vectors)",
     hbm_bytes_by_kernel={e["kernel"]: e["hbm_read_bytes"] + e["hbm_write_bytes"] for e in big
-                         if e["kernel"].endswith("[grid=1048576]") or e["kernel"].startswith(("k_window_sort", "k_decode", "k_blocks"))},
+                         if full_size(e["kernel"])},
     valu={e["kernel"]: dict(valu_wave_insts=e["counters"]["SQ_INSTS_VALU"], valu_issue_busy_frac=e["valu_issue_busy_frac"])
-          for e in per_kernel if "valu_issue_busy_frac" in e and e["kernel"].startswith("k_assign_fast") and e["kernel"].endswith("[grid=1048576]")},
+          for e in per_kernel if "valu_issue_busy_frac" in e and e["kernel"].startswith("k_assign_fast") and grid_of(e["kernel"]) >= 1048576},
     note="FETCH_SIZE (KB) doubled per the gfx950 correction for wide coalesced reads; WRITE_SIZE (KB) as is; separate "
          "rocprofv3 --pmc passes over tools/prof_encode.py on the library build named above (PMC passes run at lower "
          "clocks than un-profiled runs: durations come from the kernel trace, not from these passes).")
