@@ -2235,6 +2235,172 @@ __global__ __launch_bounds__(1024) void k_fixup_pruned(const uint8_t *__restrict
     }
 }
 
+// One pass of the pruned fix-up on a codebook in global memory: the exact distances (sequential fp64) of the
+// vector at xrow to the 256 sorted positions from p0 on (lane's positions p0 + 64 q + lane; those outside
+// [0, K) do not count), reduced over the wave to the lexicographic minimum (distance, codeword index).
+__device__ __forceinline__ void fixup_pass_global(int p0, int K, int d, int lane, const uint32_t *__restrict__ bias,
+                                                  const double *__restrict__ cbT, const uint8_t *__restrict__ xrow,
+                                                  uint32_t xv0, double &cd, int &ci) {
+    int kk[4], pp[4];                                   // codeword index; (clamped) sorted position
+    bool on[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int pq = p0 + q * WAVE + lane;
+        on[q] = pq >= 0 && pq < K;
+        pp[q] = pq < 0 ? 0 : (pq < K ? pq : K - 1);       // clamped: loads stay in bounds
+        kk[q] = (int)(bias[pp[q]] & 0x7fffffffu);
+    }
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int ebase = 0; ebase < d; ebase += WAVE) {
+        const int ecount = d - ebase < WAVE ? d - ebase : WAVE;
+        uint32_t xv = xv0;
+        if (ebase > 0) xv = lane < ecount ? (uint32_t)xrow[ebase + lane] : 0u;
+        int e0 = 0;
+        for (; e0 + 8 <= ecount; e0 += 8) {
+            double c[8][4];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const size_t off = (size_t)(ebase + e0 + j) * K;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) c[j][q] = cbT[off + pp[q]];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const double xe = (double)__builtin_amdgcn_readlane(xv, e0 + j);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] += fabs(xe - c[j][q]);
+            }
+        }
+        for (; e0 < ecount; ++e0) {
+            const size_t off = (size_t)(ebase + e0) * K;
+            const double xe = (double)__builtin_amdgcn_readlane(xv, e0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] += fabs(xe - cbT[off + pp[q]]);
+        }
+    }
+    cd = __builtin_huge_val();
+    ci = 0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (on[q] && (acc[q] < cd || (acc[q] == cd && kk[q] < ci))) {
+            cd = acc[q];
+            ci = kk[q];
+        }
+    }
+    wave_argmin(cd, ci);
+}
+
+// The pruned fix-up for codebooks too large for the LDS (the transposed fp64 copy is read from global memory): a
+// workgroup of four waves takes one queued vector, and every round its waves search four chunks of 256 sorted
+// positions at once -- the four around the vector's element sum first, then the next ones on whichever sides
+// the bound from the best distance so far still leaves open -- and merge their minima through LDS.  Same
+// bound, same arithmetic and same results as k_fixup_pruned; a long range takes a quarter of the rounds.
+__global__ __launch_bounds__(256) void k_fixup_pruned_wg(const uint8_t *__restrict__ blocks,
+                                                         const uint16_t *__restrict__ perm, int64_t N, int d,
+                                                         const double *__restrict__ cbT, int K,
+                                                         const uint32_t *__restrict__ queue,
+                                                         const uint32_t *__restrict__ qcount, uint32_t qcap,
+                                                         const PrepHeader *__restrict__ hdr,
+                                                         const uint32_t *__restrict__ bias,
+                                                         const uint32_t *__restrict__ postab,
+                                                         int32_t *__restrict__ labels, double *__restrict__ min_dist,
+                                                         unsigned long long *__restrict__ sums,
+                                                         unsigned long long *__restrict__ counts, Gate gate) {
+    __shared__ double s_cd[2][4];
+    __shared__ int s_ci[2][4];
+    if (gate_closed(gate)) return;
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+    const uint32_t sub = blockIdx.x & (NQ - 1), rank = blockIdx.x / NQ, nwg = gridDim.x / NQ;
+    const uint32_t count = qcount[16 * sub];
+    if (rank >= count) return;                                  // (workgroup-uniform)
+    const uint32_t shift = hdr->shift, emax = hdr->emax, tshift = hdr->tshift, nt = hdr->nt;
+    const double scale = (double)(1u << shift);
+    queue += (size_t)sub * qcap;
+    constexpr int PASS = 4 * WAVE, ROUND = 4 * PASS;
+    int parity = 0;
+    for (uint32_t i = rank; i < count; i += nwg) {
+        int64_t nrow = (int64_t)queue[i];
+        nrow = nrow < N ? nrow : N - 1;
+        int64_t n = nrow;                                       // vector index the results are written at
+        if (perm) {                                             // `blocks` is the sorted copy: origin inside the window
+            n = (nrow & ~(int64_t)(SORT_WIN - 1)) + (int64_t)perm[nrow];
+            n = n < N ? n : N - 1;
+        }
+        const uint8_t *xrow = blocks + (size_t)nrow * d;
+        const uint32_t xv0 = lane < d ? (uint32_t)xrow[lane] : 0u;
+        uint32_t part = xv0;
+        for (int e = lane + WAVE; e < d; e += WAVE) part += xrow[e];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, WAVE);
+        const uint32_t sx = part << shift;
+        double best = __builtin_huge_val();
+        int bidx = 0x7fffffff;
+        // one round: wave w searches the chunk at p[w] (a chunk wholly outside [0, K) is skipped), then all
+        // waves take the minimum of the four results
+        auto round = [&](int p0w) {
+            double cd = __builtin_huge_val();
+            int ci = 0x7fffffff;
+            if (p0w < K && p0w + PASS > 0) fixup_pass_global(p0w, K, d, lane, bias, cbT, xrow, xv0, cd, ci);
+            if (lane == 0) {
+                s_cd[parity][wv] = cd;
+                s_ci[parity][wv] = ci;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const double od = s_cd[parity][w];
+                const int oi = s_ci[parity][w];
+                if (od < best || (od == best && oi < bidx)) {
+                    best = od;
+                    bidx = oi;
+                }
+            }
+            parity ^= 1;                                        // the other buffer next time: no second barrier
+        };
+        int lo_done = (int)postab[sx >> tshift] - ROUND / 2;     // first round: the 1024 positions around the vector's sum
+        if (lo_done > K - ROUND) lo_done = K - ROUND;
+        if (lo_done < 0) lo_done = 0;
+        int hi_done = lo_done + ROUND;
+        round(lo_done + wv * PASS);
+        for (;;) {
+            // positions that can still hold a codeword no further away than `best`
+            const double t = ceil(best * scale) + (double)emax + 1.0;
+            const uint32_t thr = t < 4.0e9 ? (uint32_t)t : 0xffffffffu;
+            const uint32_t lo_sum = sx > thr ? sx - thr : 0u;
+            unsigned long long ih = (((unsigned long long)sx + thr) >> tshift) + 1ull;
+            if (ih > nt + 1ull) ih = nt + 1ull;
+            const int klo = (int)postab[lo_sum >> tshift];
+            const int khi = (int)postab[ih];
+            const bool need_lo = klo < lo_done, need_hi = khi > hi_done;
+            if (!need_lo && !need_hi) break;
+            int p0w;
+            if (need_lo && need_hi) {                           // two chunks on each side
+                p0w = wv < 2 ? lo_done - (wv + 1) * PASS : hi_done + (wv - 2) * PASS;
+                lo_done -= 2 * PASS;
+                hi_done += 2 * PASS;
+            } else if (need_lo) {
+                p0w = lo_done - (wv + 1) * PASS;
+                lo_done -= ROUND;
+            } else {
+                p0w = hi_done + wv * PASS;
+                hi_done += ROUND;
+            }
+            round(p0w);
+        }
+        if (threadIdx.x == 0) {
+            labels[n] = bidx;
+            if (min_dist) min_dist[n] = best;
+        }
+        if (sums && wv == 0) {
+            for (int e = lane; e < d; e += WAVE) {
+                const unsigned v = xrow[e];
+                if (v) atomicAdd(&sums[(size_t)bidx * d + e], (unsigned long long)v);
+            }
+            if (lane == 0) atomicAdd(&counts[bidx], 1ull);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // numpy-order sum of an fp64 vector (the np.mean of VQ_Full.py:90 before its division)
 // ------------------------------------------------------------------------------------------------
@@ -3184,7 +3350,7 @@ int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int
             hipLaunchKernelGGL(k_fixup_pruned<true>, dim3((di.cus + 3) / 4 * 4), dim3(1024), fx_lds, st, fx_rows, fx_perm, N, d,
                                cbT, K, queue, qcount, qcap, hdr, bias, postab, labels, min_dist, sums, counts, g_gate);
         } else {
-            hipLaunchKernelGGL(k_fixup_pruned<false>, dim3((di.cus * 4 + 15) / 16 * 16), dim3(256), 0, st, fx_rows, fx_perm, N, d,
+            hipLaunchKernelGGL(k_fixup_pruned_wg, dim3((di.cus * 8 + NQ - 1) / NQ * NQ), dim3(256), 0, st, fx_rows, fx_perm, N, d,
                                cbT, K, queue, qcount, qcap, hdr, bias, postab, labels, min_dist, sums, counts, g_gate);
         }
         LAUNCH_CHECK("k_fixup_pruned");
