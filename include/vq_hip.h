@@ -207,7 +207,9 @@ int vq_lbg_split(const double *cb, int K, int d, double eps, double *cb2, void *
 /* Decode.  Replaces the loop of Codebook.decompress (VQ_Full.py:157-169):
  * img[r*bh+i, q*bw+j, ch] = (uint8) trunc(cb[labels[r*nc+q], i, j, ch]) with the conversion
  * wrapping modulo 256 as numpy's does; img is (nr*bh, nc*bw, C) uint8 (padded size, not cropped).
- * Labels outside [0, K) make the call undefined, as an out-of-range index does in the reference. */
+ * A label outside [0, K) is an error of the caller (the reference raises IndexError, VQ_Full.py:162, and the
+ * Python wrapper checks labels before it calls): the kernels decode it as codeword K - 1 rather than read
+ * outside the codebook. */
 int vq_decode_u8(const int32_t *labels, int nr, int nc, const double *cb, int K, int bh, int bw, int C,
                  uint8_t *img, void *ws, size_t ws_bytes, void *stream);
 

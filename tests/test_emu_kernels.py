@@ -299,3 +299,17 @@ def test_emu_pruned_search_lds_tiled(eng, oracle, K, d, N):
     assert np.array_equal(labels.numpy(), want["labels"])
     assert np.array_equal(a[: K * d].reshape(K, d), want["sums"]) and np.array_equal(a[K * d:], want["counts"])
     assert dist.item() == oracle.numpy_sum(want["min_dist"])
+
+
+def test_emu_decode_keeps_stray_labels_inside_the_codebook(eng, oracle):
+    """A label outside [0, K) is the caller's error; the kernels must still not read outside the codebook
+    (guard pages end the run if they do) and decode it as codeword K - 1."""
+    rng = np.random.default_rng(3)
+    for K, bh, bw, C, nr, nc in [(20, 4, 4, 1, 6, 8), (7, 2, 2, 3, 5, 8), (9, 3, 3, 1, 4, 5)]:
+        cb = rng.random((K, bh * bw * C)) * 255.0
+        labels = rng.integers(0, K, size=(nr, nc)).astype(np.int32)
+        bad = labels.copy()
+        bad[1, 2], bad[3, 0] = K + 1000, -5
+        want = labels.copy()
+        want[1, 2] = want[3, 0] = K - 1
+        assert np.array_equal(eng.decode(T(bad), T(cb), bh, bw, C).numpy(), oracle.decode_u8(want, cb, bh, bw, C))

@@ -2786,7 +2786,7 @@ __global__ __launch_bounds__(256) void k_decode_u8(const int32_t *__restrict__ l
         uint8_t *orow = img + (size_t)y * rowbytes;
         for (uint32_t xb = blockIdx.x * blockDim.x + threadIdx.x; xb < rowbytes; xb += gridDim.x * blockDim.x) {
             const uint32_t q = xb / seg, rem = xb - q * seg;
-            orow[xb] = cb8[(size_t)lrow[q] * d + i * seg + rem];
+            orow[xb] = cb8[(size_t)min((uint32_t)lrow[q], (uint32_t)K - 1u) * d + i * seg + rem];
         }
     }
 }
@@ -2821,7 +2821,7 @@ __global__ __launch_bounds__(256) void k_decode_blockrows_u8(const int32_t *__re
             uint32_t q = xb0 / seg, rem = xb0 - q * seg;
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
-                base[w] = (uint32_t)lrow[q] * d + rem;
+                base[w] = min((uint32_t)lrow[q], (uint32_t)K - 1u) * d + rem;      // a label outside [0, K) stays in bounds
                 rem += 4;
                 if (rem >= seg) {
                     rem = 0;
@@ -2872,7 +2872,9 @@ __global__ __launch_bounds__(1024) void k_decode_quads(const int32_t *__restrict
     const uint4 *cw = reinterpret_cast<const uint4 *>(LDS_CB ? s_cb8 : cb8g);
     auto emit = [&](int64_t item, const uint4 &l) {
         const uint32_t r = (uint32_t)(item / qpr), qx = (uint32_t)(item - (int64_t)r * qpr);
-        const uint4 c0 = cw[l.x], c1 = cw[l.y], c2 = cw[l.z], c3 = cw[l.w];
+        // (labels are the caller's: one outside [0, K) must not lead out of the codebook)
+        const uint32_t km = (uint32_t)K - 1u;
+        const uint4 c0 = cw[min(l.x, km)], c1 = cw[min(l.y, km)], c2 = cw[min(l.z, km)], c3 = cw[min(l.w, km)];
         uint8_t *o = img + (size_t)r * 4 * rowbytes + (size_t)qx * 16;
         *reinterpret_cast<uint4 *>(o) = make_uint4(c0.x, c1.x, c2.x, c3.x);
         *reinterpret_cast<uint4 *>(o + rowbytes) = make_uint4(c0.y, c1.y, c2.y, c3.y);
