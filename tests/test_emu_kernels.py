@@ -72,7 +72,7 @@ def test_emu_window_sort_lds_variant(eng, N, d):
 
 
 @pytest.mark.parametrize("K,d,N", [(40, 16, 1500), (5, 12, 700), (70, 48, 600), (300, 8, 900), (20, 192, 500),
-                                   (4096, 16, 1100), (33, 64, 700), (1, 16, 300)])
+                                   (4096, 16, 1100), (33, 64, 700), (1, 16, 300), (4100, 8, 500), (4200, 40, 300)])
 def test_emu_encode_full_search(eng, oracle, K, d, N):
     rng = np.random.default_rng(K + d)
     blocks, cb = _structured(rng, K, d, N)

@@ -92,7 +92,7 @@ def test_encode_random_dims(eng, oracle, d):
         assert np.array_equal(got_d.cpu().numpy(), want_d), f"distances differ, d={d} mode={mode}"
 
 
-@pytest.mark.parametrize("K", [1, 2, 3, 5, 64, 65, 255, 256, 257, 1024, 4096])
+@pytest.mark.parametrize("K", [1, 2, 3, 5, 64, 65, 255, 256, 257, 1024, 4096, 4097, 6000])
 def test_encode_codebook_sizes(eng, oracle, K):
     rng = np.random.default_rng(K)
     N, d = 2500, 16

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Random shapes on the GPU: FAST search (plain, pruned, image-fused) and the fused LBG pass against the all-fp64
+EXACT search of the same library (itself pinned to the CPU oracle by the test-suite).
+Usage: python3 tools/gpu_fuzz.py [seconds] [seed]"""
+import os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vector_quantization_amd import HipEngine
+dev = torch.device("cuda:0")
+eng = HipEngine(dev)
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t_end = time.time() + budget
+cases = 0
+while time.time() < t_end:
+    C = int(rng.choice([1, 1, 3]))
+    bh, bw = (int(v) for v in rng.choice([1, 2, 3, 4, 8], size=2))
+    d = bh * bw * C
+    if d > 192:
+        continue
+    K = int(rng.choice([1, 2, 7, 16, 31, 32, 33, 64, 100, 255, 256, 257, 400, 512, 513, 1000, 1024, 1500, 4096, 4097, 5000]))
+    H = int(rng.integers(bh, 40 * bh)) if rng.random() < 0.5 else int(rng.integers(1, 200))
+    W = int(rng.integers(bw, 60 * bw)) if rng.random() < 0.5 else int(rng.integers(1, 300))
+    if rng.random() < 0.4:                       # aligned sizes take the fast paths
+        H, W = (H // (4 * bh) + 1) * 4 * bh, (W // 16 + 1) * 16
+    kind = rng.integers(0, 3)
+    if kind == 0:
+        img = rng.integers(0, 256, size=(H, W, C), dtype=np.uint8)
+    else:
+        yy, xx = np.mgrid[0:H, 0:W]
+        base = 128 + 100 * np.sin(xx / 17.0 + rng.random() * 6) * np.cos(yy / 11.0) + rng.normal(0, 4 if kind == 1 else 0.5, (H, W))
+        img = np.clip(np.stack([base + 9 * c for c in range(C)], -1), 0, 255).astype(np.uint8)
+    timg = torch.from_numpy(img).to(dev)
+    blocks = eng.blocks_from_image(timg, bh, bw)
+    N = blocks.shape[0]
+    b_np = blocks.cpu().numpy()
+    pick = rng.integers(0, N, K)
+    cb = b_np[pick].astype(np.float64) + rng.choice([0.0, 0.0, 0.25, -0.5, 0.001], size=(K, 1)) + rng.normal(0, 0.3, (K, d)) * (rng.random() < 0.5)
+    if K > 3:
+        cb[K // 2] = cb[0]                       # duplicate row
+    tcb = torch.from_numpy(cb).to(dev)
+    want_l, want_d = eng.encode(blocks, tcb, want_dist=True, mode=0)
+    tag = f"case {cases}: H={H} W={W} C={C} {bh}x{bw} d={d} K={K} N={N} kind={kind}"
+    got_l, got_d = eng.encode(blocks, tcb, want_dist=True, mode=1)
+    assert torch.equal(got_l, want_l) and torch.equal(got_d, want_d), "plain FAST differs, " + tag
+    srt = eng.sort_blocks(blocks)
+    if srt is not None:
+        got_l, got_d = eng.encode(blocks, tcb, want_dist=True, mode=1, sorted=srt)
+        assert torch.equal(got_l, want_l) and torch.equal(got_d, want_d), "pruned FAST differs, " + tag
+    got_l, got_d = eng.encode_image(timg, bh, bw, tcb, want_dist=True)
+    assert torch.equal(got_l, want_l) and torch.equal(got_d, want_d), "image-fused differs, " + tag
+    srt2, _ = eng.sort_image(timg, bh, bw)
+    acc, dist, lab = eng.lbg_accum(None if (srt2 is not None and eng.prune_supported(K, d)) else blocks, tcb, want_labels=True,
+                                   sorted=srt2, shape=(N, d))
+    assert torch.equal(lab, want_l), "LBG labels differ, " + tag
+    sums = torch.zeros(K, d, dtype=torch.int64, device=dev).index_add_(0, want_l.long(), blocks.long())
+    counts = torch.bincount(want_l.long(), minlength=K)
+    assert torch.equal(acc[: K * d].view(K, d), sums) and torch.equal(acc[K * d:], counts), "LBG sums differ, " + tag
+    dec = eng.decode(want_l.view(-(-H // bh), -(-W // bw)), tcb, bh, bw, C)
+    ref = tcb.trunc().to(torch.int64).remainder(256).to(torch.uint8)[want_l.long()].view(-(-H // bh), -(-W // bw), bh, bw, C)
+    ref = ref.permute(0, 2, 1, 3, 4).reshape(dec.shape)
+    assert torch.equal(dec, ref), "decode differs, " + tag
+    cases += 1
+    if cases % 20 == 0:
+        print(f"{cases} cases ok, last: {tag}", flush=True)
+print(f"fuzz ok: {cases} cases in {budget:.0f} s")
