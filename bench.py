@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Benchmark of the VQ hot path on MI355X.
 
-Workload (the headline configuration, BASELINE configs[1]): one synthetic 8192 x 8192 grayscale image
+Workload (the headline configuration, configs[1] of the baseline description): one synthetic 8192 x 8192 grayscale image
 per GPU, 4x4 blocks (N = 4 194 304 block vectors of dim 16), K = 256 codebook trained by LBG on a
 2048 x 2048 crop.  One step starts from the IMAGE resident in HBM: image -> window-sorted block vectors
-(padding + block extraction + sort, one pass), codebook preparation, pruned nearest-codeword search,
-fp64 fix-up of near-ties (exact labels), decode of the labels back to an image.  `value` = block vectors
+(padding + block extraction + sort, one pass), codebook preparation, pruned nearest-codeword search with
+its near-ties re-checked in fp64 inside the same kernel (exact labels), decode of the labels back to an image.  `value` = block vectors
 through that step per second, whole job.
 
 Extra keys: the dominant kernel's roofline (executed SAD work against the v_sad_u16 issue ceiling, never
@@ -330,7 +330,7 @@ def main():
                        achieved=dec_alg / (dec_ms * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
                        frac=dec_alg / (dec_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, traffic=pmc_bytes("decode"),
                        algorithmic_bytes_per_vector=d + 4),
-        "codebook_prepare": dict(kernel="k_prepare", kernel_ms=prep_ms, note="K*d entries; latency-bound"),
+        "codebook_prepare": dict(kernel="k_prepare_small<4>", kernel_ms=prep_ms, note="K*d entries, one workgroup; latency-bound"),
     }
 
     # ---- LBG iterations (fused assign + accumulate, exchange, centroid update) ----------------------

@@ -776,7 +776,7 @@ __global__ __launch_bounds__(1024) void k_prep_finish(int K, int d, int dp2, uin
 }
 
 // Codebook preparation for short rows and small codebooks (d <= 16, K * TPC <= 1024: the LBG stages of small
-// blocks, where this launch sits on the critical path of every iteration).  Same outputs as k_prepare, with TPC
+// blocks, where this launch sits on the critical path of every iteration).  Same outputs as the four-launch form above, with TPC
 // adjacent threads per codeword: each holds 16 / TPC entries in registers from the single read of the
 // codebook to the writes at the sorted place, partial sums are combined across the TPC lanes, and the ranking
 // scan is split between them.  Global stores come last, so that nothing waits for them.
@@ -2045,14 +2045,14 @@ __global__ __launch_bounds__(1024) void k_fixup(const uint8_t *__restrict__ bloc
 }
 
 // The fix-up pass with the element-sum bound of the pruned search (needs the sorted fixed-point
-// codebook that k_prepare leaves for K <= PREP_SORT_CAP).  A wave takes one queued vector: lanes hold
+// codebook that the prepare kernels leave for K <= PREP_SORT_CAP; this kernel serves codebooks whose
+// transposed fp64 copy fits the LDS, k_fixup_pruned_wg the larger ones).  A wave takes one queued vector: lanes hold
 // 256 consecutive positions of the sorted codebook (four per lane), starting with those around the
 // vector's own element sum; after every pass the exact best distance D gives the range of positions
 // that can still hold a codeword at distance <= D (their fixed-point element sum lies within
 // D * 2^s + Emax + 1 of the vector's, looked up in postab), and the wave takes the next 256 on
 // whichever side is not covered yet.  A skipped codeword is strictly further away than the winner,
 // so label and distance equal those of the full search, ties included (lowest codeword index).
-template <bool LDS_CB>
 __global__ __launch_bounds__(1024) void k_fixup_pruned(const uint8_t *__restrict__ blocks,
                                                        const uint16_t *__restrict__ perm, int64_t N, int d,
                                                        const double *__restrict__ cbT, int K,
@@ -2077,11 +2077,11 @@ __global__ __launch_bounds__(1024) void k_fixup_pruned(const uint8_t *__restrict
         any = any || qcount[16 * (ww & (NQ - 1))] > ww / NQ;
     }
     if (!any) return;
-    // LDS_CB: the transposed codebook, the position table and the position -> codeword map are staged in LDS,
-    // so that a queued vector costs no memory round trip beyond fetching the vector itself
+    // the transposed codebook, the position table and the position -> codeword map are staged in LDS, so that a
+    // queued vector costs no memory round trip beyond fetching the vector itself
     const uint32_t *s_postab = reinterpret_cast<const uint32_t *>(s_cbT + (size_t)K * d);
     const uint32_t *s_bias = s_postab + POSTAB_WORDS;
-    if (LDS_CB) {
+    {
         const int n = K * d;
         for (int i = threadIdx.x; i < n; i += blockDim.x) s_cbT[i] = cbT[i];
         uint32_t *wp = reinterpret_cast<uint32_t *>(s_cbT + (size_t)K * d);
@@ -2164,7 +2164,7 @@ __global__ __launch_bounds__(1024) void k_fixup_pruned(const uint8_t *__restrict
                         for (int j = 0; j < 8; ++j) {
                             const size_t off = (size_t)(ebase + e0 + j) * K;
     #pragma unroll
-                            for (int q = 0; q < 4; ++q) c[j][q] = LDS_CB ? s_cbT[off + pp[q]] : cbT[off + pp[q]];
+                            for (int q = 0; q < 4; ++q) c[j][q] = s_cbT[off + pp[q]];
                         }
     #pragma unroll
                         for (int j = 0; j < 8; ++j) {
@@ -2177,7 +2177,7 @@ __global__ __launch_bounds__(1024) void k_fixup_pruned(const uint8_t *__restrict
                         const size_t off = (size_t)(ebase + e0) * K;
                         const double xe = (double)__builtin_amdgcn_readlane(xv, e0);
     #pragma unroll
-                        for (int q = 0; q < 4; ++q) acc[q] += fabs(xe - (LDS_CB ? s_cbT[off + pp[q]] : cbT[off + pp[q]]));
+                        for (int q = 0; q < 4; ++q) acc[q] += fabs(xe - (s_cbT[off + pp[q]]));
                     }
                 }
                 double cd = __builtin_huge_val();
@@ -3340,16 +3340,16 @@ int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int
     // fix-up: a fixed grid strides over the sub-queues (their lengths are only known on the device);
     // small codebooks are staged in LDS, one 1024-thread workgroup per CU
     const size_t cb_bytes = (size_t)K * d * sizeof(double);
-    // Codebooks that k_prepare sorted by element sum (their transposed fp64 copy is in sorted order too) take
+    // Codebooks that the prepare kernels sorted by element sum (their transposed fp64 copy is in sorted order too) take
     // the fix-up with the element-sum bound; larger ones are scanned whole.
     if (K <= PREP_SORT_CAP) {
         const uint32_t *postab = reinterpret_cast<const uint32_t *>(w + L.postab);
         const size_t fx_lds = cb_bytes + (size_t)(POSTAB_WORDS + K) * 4;     // codebook, position table, position map
         if (cb_bytes <= 128 * 1024) {
             if (fx_lds > 48 * 1024)
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fixup_pruned<true>),
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fixup_pruned),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)fx_lds));
-            hipLaunchKernelGGL(k_fixup_pruned<true>, dim3((di.cus + 3) / 4 * 4), dim3(1024), fx_lds, st, fx_rows, fx_perm, N, d,
+            hipLaunchKernelGGL(k_fixup_pruned, dim3((di.cus + 3) / 4 * 4), dim3(1024), fx_lds, st, fx_rows, fx_perm, N, d,
                                cbT, K, queue, qcount, qcap, hdr, bias, postab, labels, min_dist, sums, counts, g_gate);
         } else {
             hipLaunchKernelGGL(k_fixup_pruned_wg, dim3((di.cus * 8 + NQ - 1) / NQ * NQ), dim3(256), 0, st, fx_rows, fx_perm, N, d,
