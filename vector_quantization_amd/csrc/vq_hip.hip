@@ -142,6 +142,8 @@ struct WsLayout {
     size_t c16u;       // K * dp2 uint32: the same rows in original order (scratch of the prepare kernel)
     size_t postab;     // POSTAB_WORDS uint32: sum threshold -> position in the sorted codebook
     size_t prep_tmp;   // scratch of the prepare kernels: K uint64 row hashes, K uint32 element sums, K uint32 sorted sums
+    size_t c16T;       // dp2 * K uint32: the c16 rows transposed (word p of every sorted position side by side), kept
+                       // for sorted codebooks too large for the LDS of the fix-up kernel (else empty)
     size_t acc_rep;    // NREP * K * (d + 1) uint64: replicas of the [sums | count] table (fused accumulation)
     size_t cbT;        // d * K doubles: transposed fp64 codebook, columns in the order of the c16 rows
     size_t cb_u8;      // K * d bytes: codebook truncated to uint8 (decode)
@@ -152,6 +154,10 @@ struct WsLayout {
 };
 
 int dp2_bucket(int d);   // forward
+
+// Sorted codebooks whose transposed fp64 copy exceeds the LDS budget of k_fixup_pruned take k_fixup_shortlist,
+// which reads the fixed-point rows transposed.
+inline bool wants_c16T(int K, int d) { return K <= PREP_SORT_CAP && (size_t)K * d * 8 > 128 * 1024; }
 
 WsLayout ws_layout(int K, int d, int64_t N) {
     WsLayout L;
@@ -165,6 +171,7 @@ WsLayout ws_layout(int K, int d, int64_t N) {
     L.c16u = off;     off += align_up((size_t)K * dp2 * 4, 256);
     L.postab = off;   off += align_up((size_t)POSTAB_WORDS * 4, 256);
     L.prep_tmp = off; off += align_up((size_t)K * 16, 256);
+    L.c16T = off;     off += wants_c16T(K, d) ? align_up((size_t)K * dp2 * 4, 256) : 0;
     L.acc_rep = off;  off += (size_t)K * (d + 1) * 4 <= 40 * 1024 ? align_up((size_t)NREP * K * (d + 1) * 8, 256) : 0;
     L.cbT = off;      off += align_up((size_t)K * d * 8, 256);
     L.cb_u8 = off;    off += align_up((size_t)K * d, 256);
@@ -667,7 +674,7 @@ __global__ __launch_bounds__(256) void k_prep_rank(const double *__restrict__ cb
                                                    const uint32_t *__restrict__ sc, const unsigned long long *__restrict__ hash,
                                                    const uint32_t *__restrict__ c16u, uint32_t *__restrict__ c16,
                                                    uint32_t *__restrict__ bias, double *__restrict__ cbT,
-                                                   uint32_t *__restrict__ scs) {
+                                                   uint32_t *__restrict__ scs, uint32_t *__restrict__ c16T) {
     extern __shared__ __align__(16) unsigned long long s_prep[];
     __shared__ uint32_t s_pos[PREP_RANK_ROWS];
     const int kq = (K + 3) & ~3;
@@ -731,7 +738,11 @@ __global__ __launch_bounds__(256) void k_prep_rank(const double *__restrict__ cb
         const int k2 = blockIdx.x * PREP_RANK_ROWS + rr;
         if (k2 < K) {                                                           // (wave-uniform)
             const uint32_t p2 = s_pos[rr];
-            for (int p = lane; p < dp2; p += WAVE) c16[(size_t)p2 * dp2 + p] = c16u[(size_t)k2 * dp2 + p];
+            for (int p = lane; p < dp2; p += WAVE) {
+                const uint32_t w = c16u[(size_t)k2 * dp2 + p];
+                c16[(size_t)p2 * dp2 + p] = w;
+                if (c16T) c16T[(size_t)p * K + p2] = w;                        // (nullable: only large codebooks keep it)
+            }
             for (int e = lane; e < d; e += WAVE) cbT[(size_t)e * K + p2] = cb[(size_t)k2 * d + e];
         }
     }
@@ -2046,7 +2057,7 @@ __global__ __launch_bounds__(1024) void k_fixup(const uint8_t *__restrict__ bloc
 
 // The fix-up pass with the element-sum bound of the pruned search (needs the sorted fixed-point
 // codebook that the prepare kernels leave for K <= PREP_SORT_CAP; this kernel serves codebooks whose
-// transposed fp64 copy fits the LDS, k_fixup_pruned_wg the larger ones).  A wave takes one queued vector: lanes hold
+// transposed fp64 copy fits the LDS, k_fixup_shortlist the larger ones).  A wave takes one queued vector: lanes hold
 // 256 consecutive positions of the sorted codebook (four per lane), starting with those around the
 // vector's own element sum; after every pass the exact best distance D gives the range of positions
 // that can still hold a codeword at distance <= D (their fixed-point element sum lies within
@@ -2235,70 +2246,21 @@ __global__ __launch_bounds__(1024) void k_fixup_pruned(const uint8_t *__restrict
     }
 }
 
-// One pass of the pruned fix-up on a codebook in global memory: the exact distances (sequential fp64) of the
-// vector at xrow to the 256 sorted positions from p0 on (lane's positions p0 + 64 q + lane; those outside
-// [0, K) do not count), reduced over the wave to the lexicographic minimum (distance, codeword index).
-__device__ __forceinline__ void fixup_pass_global(int p0, int K, int d, int lane, const uint32_t *__restrict__ bias,
-                                                  const double *__restrict__ cbT, const uint8_t *__restrict__ xrow,
-                                                  uint32_t xv0, double &cd, int &ci) {
-    int kk[4], pp[4];                                   // codeword index; (clamped) sorted position
-    bool on[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int pq = p0 + q * WAVE + lane;
-        on[q] = pq >= 0 && pq < K;
-        pp[q] = pq < 0 ? 0 : (pq < K ? pq : K - 1);       // clamped: loads stay in bounds
-        kk[q] = (int)(bias[pp[q]] & 0x7fffffffu);
-    }
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int ebase = 0; ebase < d; ebase += WAVE) {
-        const int ecount = d - ebase < WAVE ? d - ebase : WAVE;
-        uint32_t xv = xv0;
-        if (ebase > 0) xv = lane < ecount ? (uint32_t)xrow[ebase + lane] : 0u;
-        int e0 = 0;
-        for (; e0 + 8 <= ecount; e0 += 8) {
-            double c[8][4];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const size_t off = (size_t)(ebase + e0 + j) * K;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) c[j][q] = cbT[off + pp[q]];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const double xe = (double)__builtin_amdgcn_readlane(xv, e0 + j);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] += fabs(xe - c[j][q]);
-            }
-        }
-        for (; e0 < ecount; ++e0) {
-            const size_t off = (size_t)(ebase + e0) * K;
-            const double xe = (double)__builtin_amdgcn_readlane(xv, e0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] += fabs(xe - cbT[off + pp[q]]);
-        }
-    }
-    cd = __builtin_huge_val();
-    ci = 0x7fffffff;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (on[q] && (acc[q] < cd || (acc[q] == cd && kk[q] < ci))) {
-            cd = acc[q];
-            ci = kk[q];
-        }
-    }
-    wave_argmin(cd, ci);
-}
-
-// The pruned fix-up for codebooks too large for the LDS (the transposed fp64 copy is read from global memory): a
-// workgroup of four waves takes one queued vector, and every round its waves search four chunks of 256 sorted
-// positions at once -- the four around the vector's element sum first, then the next ones on whichever sides
-// the bound from the best distance so far still leaves open -- and merge their minima through LDS.  Same
-// bound, same arithmetic and same results as k_fixup_pruned; a long range takes a quarter of the rounds.
-__global__ __launch_bounds__(256) void k_fixup_pruned_wg(const uint8_t *__restrict__ blocks,
-                                                         const uint16_t *__restrict__ perm, int64_t N, int d,
-                                                         const double *__restrict__ cbT, int K,
-                                                         const uint32_t *__restrict__ queue,
+// The fix-up of a queued vector for sorted codebooks beyond the LDS, without reading the fp64 codebook for more
+// than a handful of rows (measuring every searched row in fp64 reads 8 d bytes per row and is bound by the L2).  The
+// workgroup (four waves) repeats the filter's search for this one vector with lanes over codewords -- the
+// fixed-point SAD of every sorted position whose element sum lies within (smallest SAD so far + ambiguity
+// window) of the vector's, 1024 positions per round, read from the transposed fixed-point rows (coalesced,
+// d bytes per row), the SADs kept in LDS -- which yields the exact smallest SAD and with it the complete list
+// of rows that can be the fp64 argmin (SAD within the window of the smallest: |T_k - S_k| <= Emax for every
+// row).  Only those rows are measured in fp64: the terms |x_e - c_e| in parallel, their sum in element order.
+// The lowest codeword index wins ties.  A list that overflows (more than FIX_LIST rows within the window:
+// constructed inputs) makes the workgroup measure the whole searched range.
+constexpr int FIX_LIST = 128;
+__global__ __launch_bounds__(256) void k_fixup_shortlist(const uint8_t *__restrict__ blocks,
+                                                         const uint16_t *__restrict__ perm, int64_t N, int d, int dp2,
+                                                         const double *__restrict__ cbrows, const uint32_t *__restrict__ c16T,
+                                                         int K, const uint32_t *__restrict__ queue,
                                                          const uint32_t *__restrict__ qcount, uint32_t qcap,
                                                          const PrepHeader *__restrict__ hdr,
                                                          const uint32_t *__restrict__ bias,
@@ -2306,15 +2268,22 @@ __global__ __launch_bounds__(256) void k_fixup_pruned_wg(const uint8_t *__restri
                                                          int32_t *__restrict__ labels, double *__restrict__ min_dist,
                                                          unsigned long long *__restrict__ sums,
                                                          unsigned long long *__restrict__ counts, Gate gate) {
-    __shared__ double s_cd[2][4];
-    __shared__ int s_ci[2][4];
+    __shared__ uint32_t s_sad[PREP_SORT_CAP];               // SAD of every searched position
+    __shared__ uint32_t s_xw[MAX_D_FAST / 2];               // the vector in the fixed point of the codebook rows
+    __shared__ double s_xd[MAX_D_FAST];                     // the vector as doubles
+    __shared__ double s_term[4 * MAX_D_FAST];               // per wave: the terms of one distance
+    __shared__ uint32_t s_min[2][4];
+    __shared__ uint32_t s_list[FIX_LIST];
+    __shared__ uint32_t s_nlist;
+    __shared__ double s_cd[4];
+    __shared__ int s_ci[4];
     if (gate_closed(gate)) return;
-    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
     const uint32_t sub = blockIdx.x & (NQ - 1), rank = blockIdx.x / NQ, nwg = gridDim.x / NQ;
     const uint32_t count = qcount[16 * sub];
     if (rank >= count) return;                                  // (workgroup-uniform)
     const uint32_t shift = hdr->shift, emax = hdr->emax, tshift = hdr->tshift, nt = hdr->nt;
-    const double scale = (double)(1u << shift);
+    const uint32_t window = emax >= 0x3fffffffu ? 0xffffffffu : 2u * emax;
     queue += (size_t)sub * qcap;
     constexpr int PASS = 4 * WAVE, ROUND = 4 * PASS;
     int parity = 0;
@@ -2327,34 +2296,62 @@ __global__ __launch_bounds__(256) void k_fixup_pruned_wg(const uint8_t *__restri
             n = n < N ? n : N - 1;
         }
         const uint8_t *xrow = blocks + (size_t)nrow * d;
-        const uint32_t xv0 = lane < d ? (uint32_t)xrow[lane] : 0u;
-        uint32_t part = xv0;
-        for (int e = lane + WAVE; e < d; e += WAVE) part += xrow[e];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, WAVE);
-        const uint32_t sx = part << shift;
-        double best = __builtin_huge_val();
-        int bidx = 0x7fffffff;
-        // one round: wave w searches the chunk at p[w] (a chunk wholly outside [0, K) is skipped), then all
-        // waves take the minimum of the four results
+        __syncthreads();                                        // the previous vector's LDS state is no longer read
+        for (int p = tid; p < dp2; p += 256) {
+            const uint32_t b0 = 2 * p < d ? xrow[2 * p] : 0u, b1 = 2 * p + 1 < d ? xrow[2 * p + 1] : 0u;
+            s_xw[p] = (b0 | (b1 << 16)) << shift;
+        }
+        for (int e = tid; e < d; e += 256) s_xd[e] = (double)xrow[e];
+        if (tid == 0) s_nlist = 0u;
+        __syncthreads();
+        uint32_t sx = 0;                                        // element sum in the units of the codebook rows
+        for (int p = 0; p < dp2; ++p) sx = __builtin_amdgcn_sad_u16(s_xw[p], 0u, sx);
+        sx = __builtin_amdgcn_readfirstlane(sx);
+        uint32_t smin = 0xffffffffu;                            // smallest SAD so far (workgroup-uniform)
+        // one round: wave w takes the 256 positions from p0w on (four per lane; those outside [0, K) do not count)
         auto round = [&](int p0w) {
-            double cd = __builtin_huge_val();
-            int ci = 0x7fffffff;
-            if (p0w < K && p0w + PASS > 0) fixup_pass_global(p0w, K, d, lane, bias, cbT, xrow, xv0, cd, ci);
-            if (lane == 0) {
-                s_cd[parity][wv] = cd;
-                s_ci[parity][wv] = ci;
-            }
-            __syncthreads();
+            int pc[4];                                          // (clamped) positions: loads stay in bounds
+            bool on[4];
+            uint32_t sad[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const double od = s_cd[parity][w];
-                const int oi = s_ci[parity][w];
-                if (od < best || (od == best && oi < bidx)) {
-                    best = od;
-                    bidx = oi;
+            for (int q = 0; q < 4; ++q) {
+                const int pos = p0w + q * WAVE + lane;
+                on[q] = pos >= 0 && pos < K;
+                pc[q] = pos < 0 ? 0 : (pos < K ? pos : K - 1);
+            }
+            if (p0w < K && p0w + PASS > 0) {                    // (wave-uniform) a chunk wholly outside is skipped
+                int p = 0;
+                for (; p + 8 <= dp2; p += 8) {                  // 32 loads in flight, then the SADs
+                    uint32_t c[8][4];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) c[j][q] = c16T[(size_t)(p + j) * K + pc[q]];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint32_t x = s_xw[p + j];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) sad[q] = __builtin_amdgcn_sad_u16(c[j][q], x, sad[q]);
+                    }
+                }
+                for (; p < dp2; ++p) {
+                    const uint32_t x = s_xw[p];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) sad[q] = __builtin_amdgcn_sad_u16(c16T[(size_t)p * K + pc[q]], x, sad[q]);
                 }
             }
+            uint32_t wmin = 0xffffffffu;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (on[q]) {
+                    s_sad[pc[q]] = sad[q];
+                    wmin = sad[q] < wmin ? sad[q] : wmin;
+                }
+            wmin = wave_reduce_u32<false>(wmin);
+            if (lane == 0) s_min[parity][wv] = wmin;
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < 4; ++w) smin = min(smin, s_min[parity][w]);
             parity ^= 1;                                        // the other buffer next time: no second barrier
         };
         int lo_done = (int)postab[sx >> tshift] - ROUND / 2;     // first round: the 1024 positions around the vector's sum
@@ -2362,12 +2359,12 @@ __global__ __launch_bounds__(256) void k_fixup_pruned_wg(const uint8_t *__restri
         if (lo_done < 0) lo_done = 0;
         int hi_done = lo_done + ROUND;
         round(lo_done + wv * PASS);
+        uint32_t lim;
         for (;;) {
-            // positions that can still hold a codeword no further away than `best`
-            const double t = ceil(best * scale) + (double)emax + 1.0;
-            const uint32_t thr = t < 4.0e9 ? (uint32_t)t : 0xffffffffu;
-            const uint32_t lo_sum = sx > thr ? sx - thr : 0u;
-            unsigned long long ih = (((unsigned long long)sx + thr) >> tshift) + 1ull;
+            // positions that can still hold a row within the window of the smallest SAD
+            lim = smin + window < smin ? 0xffffffffu : smin + window;
+            const uint32_t lo_sum = sx > lim ? sx - lim : 0u;
+            unsigned long long ih = (((unsigned long long)sx + lim) >> tshift) + 1ull;
             if (ih > nt + 1ull) ih = nt + 1ull;
             const int klo = (int)postab[lo_sum >> tshift];
             const int khi = (int)postab[ih];
@@ -2387,7 +2384,59 @@ __global__ __launch_bounds__(256) void k_fixup_pruned_wg(const uint8_t *__restri
             }
             round(p0w);
         }
-        if (threadIdx.x == 0) {
+        const int a0 = lo_done > 0 ? lo_done : 0, a1 = hi_done < K ? hi_done : K;       // searched positions
+        // the rows within the window of the smallest SAD
+        for (int pos = a0 + tid; pos < a1; pos += 256)
+            if (s_sad[pos] <= lim) {
+                const uint32_t slot = atomicAdd(&s_nlist, 1u);
+                if (slot < (uint32_t)FIX_LIST) s_list[slot] = (uint32_t)pos;
+            }
+        __syncthreads();
+        const uint32_t nl = s_nlist;
+        const bool whole = nl > (uint32_t)FIX_LIST;             // overflow: every searched row is measured
+        const uint32_t ncand = whole ? (uint32_t)(a1 - a0) : nl;
+        double best = __builtin_huge_val();
+        int bidx = 0x7fffffff;
+        double *term = s_term + wv * MAX_D_FAST;
+        for (uint32_t c = wv; c < ncand; c += 4) {              // (wave-uniform) one row per wave and trip
+            const int pos = whole ? a0 + (int)c : (int)s_list[c];
+            const int kk = (int)(bias[pos] & 0x7fffffffu);
+            const double *crow = cbrows + (size_t)kk * d;
+            // the terms |x_e - c_e| in parallel (lanes over elements, one coalesced read of the row), then their
+            // sum in element order from LDS: the additions of the sequential loop without its round trips
+            for (int e = lane; e < d; e += WAVE) term[e] = fabs(s_xd[e] - crow[e]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            double acc = 0.0;
+            int e = 0;
+            for (; e + 8 <= d; e += 8) {
+                double t[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = term[e + j];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc += t[j];
+            }
+            for (; e < d; ++e) acc += term[e];                  // the same value in every lane
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (acc < best || (acc == best && kk < bidx)) {
+                best = acc;
+                bidx = kk;
+            }
+        }
+        if (lane == 0) {
+            s_cd[wv] = best;
+            s_ci[wv] = bidx;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const double od = s_cd[w];
+            const int oi = s_ci[w];
+            if (od < best || (od == best && oi < bidx)) {
+                best = od;
+                bidx = oi;
+            }
+        }
+        if (tid == 0) {
             labels[n] = bidx;
             if (min_dist) min_dist[n] = best;
         }
@@ -3155,7 +3204,8 @@ int run_prepare(const double *cb, int K, int d, void *ws, hipStream_t st) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_prep_rank), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
         hipLaunchKernelGGL(k_prep_rank, dim3((K + PREP_RANK_ROWS - 1) / PREP_RANK_ROWS), dim3(256), lds, st, cb, K, d, dp2, sc,
-                           hash, c16u, c16, bias, cbT, scs);
+                           hash, c16u, c16, bias, cbT, scs,
+                           wants_c16T(K, d) ? reinterpret_cast<uint32_t *>(w + L.c16T) : nullptr);
         LAUNCH_CHECK("k_prep_rank");
     }
     hipLaunchKernelGGL(k_prep_finish, dim3(1), dim3(1024), 0, st, K, d, dp2, clim, do_sort ? 1 : 0, hdr, scs, c16, bias, postab);
@@ -3352,8 +3402,9 @@ int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int
             hipLaunchKernelGGL(k_fixup_pruned, dim3((di.cus + 3) / 4 * 4), dim3(1024), fx_lds, st, fx_rows, fx_perm, N, d,
                                cbT, K, queue, qcount, qcap, hdr, bias, postab, labels, min_dist, sums, counts, g_gate);
         } else {
-            hipLaunchKernelGGL(k_fixup_pruned_wg, dim3((di.cus * 8 + NQ - 1) / NQ * NQ), dim3(256), 0, st, fx_rows, fx_perm, N, d,
-                               cbT, K, queue, qcount, qcap, hdr, bias, postab, labels, min_dist, sums, counts, g_gate);
+            hipLaunchKernelGGL(k_fixup_shortlist, dim3((di.cus * 8 + NQ - 1) / NQ * NQ), dim3(256), 0, st, fx_rows, fx_perm, N, d,
+                               dp2, cb, reinterpret_cast<const uint32_t *>(w + L.c16T), K, queue, qcount, qcap, hdr, bias, postab,
+                               labels, min_dist, sums, counts, g_gate);
         }
         LAUNCH_CHECK("k_fixup_pruned");
     } else if (cb_bytes <= 64 * 1024) {
