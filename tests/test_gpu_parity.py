@@ -179,6 +179,25 @@ def test_encode_codebook_out_of_pixel_range(eng, oracle):
         assert np.array_equal(got, want), f"top={top}"
 
 
+@pytest.mark.parametrize("K,d", [(40, 48), (600, 16), (1100, 8)])
+def test_encode_codebook_out_of_pixel_range_other_shapes(eng, oracle, K, d):
+    """The same through the multi-workgroup codebook preparation, plain and pruned search."""
+    rng = np.random.default_rng(K + d)
+    N = 2500
+    blocks = rng.integers(0, 256, size=(N, d), dtype=np.uint8)
+    for top in (257.55, 600.0, 70000.0, -5.0):
+        cb = rng.random((K, d)) * 255.0
+        cb[2] = top
+        cb[5, 3] = top
+        cb[K - 1] = cb[7]                                   # and a duplicate row
+        want_l, want_d = oracle.encode_l1(blocks, cb, want_dist=True)
+        b = dev(blocks)
+        for srt in (None, eng.sort_blocks(b)):
+            got_l, got_d = eng.encode(b, dev(cb), want_dist=True, sorted=srt)
+            assert np.array_equal(got_l.cpu().numpy(), want_l), f"top={top} sorted={srt is not None}"
+            assert np.array_equal(got_d.cpu().numpy(), want_d), f"top={top} sorted={srt is not None}"
+
+
 def test_encode_empty_and_tiny(eng, oracle):
     cb = np.arange(32, dtype=np.float64).reshape(2, 16)
     got = eng.encode(dev(np.zeros((0, 16), dtype=np.uint8)), dev(cb))
