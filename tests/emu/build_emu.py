@@ -54,18 +54,30 @@ def transform(text):
     return text
 
 
+def _fresh(deps):
+    return os.path.isfile(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(p) for p in deps)
+
+
 def build(force=False):
+    """Several test processes may ask for the library at once (spawned ranks): the build runs under a file
+    lock and the library appears under its name only when it is complete."""
+    import fcntl
     os.makedirs(OUT_DIR, exist_ok=True)
     deps = [SRC, os.path.join(HERE, "hip", "hip_runtime.h"), os.path.abspath(__file__)]
-    if not force and os.path.isfile(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(p) for p in deps):
+    if not force and _fresh(deps):
         return OUT
-    cpp = os.path.join(OUT_DIR, "vq_hip_emu.cpp")
-    with open(cpp, "w") as f:
-        f.write(transform(open(SRC).read()))
-    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-pthread", "-w",
-
-           "-I", HERE, "-I", os.path.join(ROOT, "include"), cpp, "-o", OUT]
-    subprocess.run(cmd, check=True)
+    with open(os.path.join(OUT_DIR, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and _fresh(deps):          # another process built it while this one waited
+            return OUT
+        cpp = os.path.join(OUT_DIR, "vq_hip_emu.cpp")
+        with open(cpp, "w") as f:
+            f.write(transform(open(SRC).read()))
+        tmp = OUT + f".{os.getpid()}.tmp"
+        cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-pthread", "-w",
+               "-I", HERE, "-I", os.path.join(ROOT, "include"), cpp, "-o", tmp]
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, OUT)
     return OUT
 
 

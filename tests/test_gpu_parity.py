@@ -699,3 +699,105 @@ def test_full_size_image_fused_encode(eng):
     got, got_d = eng.encode_image(img, 4, 4, cb, want_dist=True)
     assert torch.equal(got, want) and torch.equal(got_d, want_d)
     assert torch.equal(got, eng.encode(blocks, cb, mode=0))
+
+
+# ---------------------------------------------------------------------------------------------------
+# 16384 x 16384 grayscale, 4x4 blocks, LBG to K = 1024: the full training workload at its real size
+# ---------------------------------------------------------------------------------------------------
+def test_full_size_k1024_training_properties(eng, oracle):
+    """N = 16 777 216 vectors is beyond what the CPU oracle trains in seconds, so the run is checked through
+    what does not depend on size: the device-side stage loop (stop rule of VQ_Full.py:89-98 on the device,
+    fused search + accumulation while the table fits) against a host-driven replay of VQ_Full.py:70-98 built
+    from the separate entry points with the unpruned search, the partition of the data by the last
+    assignment, numpy's distance sum, the all-fp64 search on a quarter of the vectors and the CPU oracle
+    on a sample."""
+    from vector_quantization_amd import train_lbg, lbg_iteration
+    from vector_quantization_amd.lbg import initial_centroid
+    img = _structured(16384, 16384, 5)
+    blocks = eng.blocks_from_image(img, 4, 4)
+    del img
+    N = blocks.shape[0]
+    assert blocks.shape == (4096 * 4096, 16)
+    res = train_lbg(eng, blocks, 1024, log=None)
+    assert res.codebook.shape == (1024, 16) and len(res.iters_per_stage) == 10
+    assert len(res.distortions) == sum(res.iters_per_stage)
+    # host-driven replay: split, assign without the sorted copy, centroid update, stop rule in Python
+    cb, n_total = initial_centroid(eng, blocks)
+    assert n_total == N
+    iters, dists = [], []
+    while cb.shape[0] < 1024:
+        cb = eng.lbg_split(cb, 0.01)
+        prev, done = float("inf"), 0
+        for _ in range(100):
+            cb, distortion = lbg_iteration(eng, blocks, cb, n_total)
+            dists.append(distortion)
+            done += 1
+            if prev != float("inf") and prev != 0.0 and abs(prev - distortion) / prev < 0.001:
+                break
+            prev = distortion
+        iters.append(done)
+    assert iters == list(res.iters_per_stage)
+    assert dists == list(res.distortions)
+    assert torch.equal(cb, res.codebook)
+    # the final codebook: pruned search == unpruned search everywhere, == all-fp64 search on a quarter
+    srt = eng.sort_blocks(blocks)
+    lab_p, mind_p = eng.encode(blocks, cb, mode=1, sorted=srt, want_dist=True)
+    lab_f, mind_f = eng.encode(blocks, cb, mode=1, want_dist=True)
+    assert torch.equal(lab_p, lab_f) and torch.equal(mind_p, mind_f)
+    q = N // 4
+    lab_x, mind_x = eng.encode(blocks[2 * q: 3 * q], cb, mode=0, want_dist=True)
+    assert torch.equal(lab_x, lab_p[2 * q: 3 * q]) and torch.equal(mind_x, mind_p[2 * q: 3 * q])
+    idx = torch.randperm(N, device="cuda:0")[:20000]
+    assert np.array_equal(lab_p[idx].cpu().numpy(), oracle.encode_l1(blocks[idx].cpu().numpy(), cb.cpu().numpy()))
+    # one more pass: a partition of the data, numpy's distance sum, the same with and without the sorted copy
+    acc, dist, lab_a = eng.lbg_accum(blocks, cb, want_labels=True, sorted=srt)
+    acc2, dist2 = eng.lbg_accum(blocks, cb)
+    assert torch.equal(acc, acc2) and dist.item() == dist2.item() and torch.equal(lab_a, lab_p)
+    assert int(acc[1024 * 16:].sum().item()) == N
+    assert torch.equal(acc[: 1024 * 16].reshape(1024, 16).sum(0), eng.colsum(blocks))
+    assert torch.equal(acc[1024 * 16:], torch.bincount(lab_p.long(), minlength=1024))
+    assert dist.item() == float(np.add.reduce(mind_p.cpu().numpy()))
+
+
+# ---------------------------------------------------------------------------------------------------
+# a batch of 512 images of 2048 x 2048 (one GPU's share of 4096 images over 8 GPUs): N = 2^27 vectors
+# ---------------------------------------------------------------------------------------------------
+def test_batch_share_of_one_gpu_encode_decode(eng, oracle):
+    """The images of a batch are independent and 4 divides their height, so the batch is one tall image:
+    2 GiB of pixels, 2^31 bytes of block vectors -- every byte offset beyond 32 bits is exercised.  Labels of
+    the whole batch in one call equal the labels of single images encoded on their own (first, middle, last),
+    the all-fp64 search on the last image, and the CPU oracle on a sample drawn from the whole batch."""
+    from vector_quantization_amd import train_lbg
+    n_img, side = 512, 2048
+    per = (side // 4) ** 2
+    batch = torch.empty((n_img, side, side), dtype=torch.uint8, device="cuda:0")
+    for i in range(0, n_img, 64):
+        batch[i: i + 64] = _structured(64 * side, side, 100 + i).view(64, side, side)
+    cb = train_lbg(eng, eng.blocks_from_image(batch[7], 4, 4), 256, log=None).codebook
+    tall = batch.view(n_img * side, side)
+    labels = eng.encode_image(tall, 4, 4, cb)
+    assert labels.numel() == n_img * per
+    labels = labels.view(n_img, per)
+    for i in (0, 255, n_img - 1):
+        assert torch.equal(eng.encode_image(batch[i], 4, 4, cb).reshape(-1), labels[i])
+    last = eng.blocks_from_image(batch[n_img - 1], 4, 4)
+    assert torch.equal(eng.encode(last, cb, mode=0).reshape(-1), labels[n_img - 1])
+    # block extraction over the whole batch, then a sample against the CPU oracle
+    blocks = eng.blocks_from_image(tall, 4, 4)
+    assert blocks.shape == (n_img * per, 16)
+    assert torch.equal(blocks[(n_img - 1) * per:], last)
+    idx = torch.randint(0, n_img * per, (20000,), device="cuda:0")
+    idx[:4] = torch.tensor([0, 1, n_img * per - 2, n_img * per - 1], device="cuda:0")
+    want = oracle.encode_l1(blocks[idx].cpu().numpy(), cb.cpu().numpy())
+    assert np.array_equal(labels.reshape(-1)[idx].cpu().numpy(), want)
+    # search on the block matrix (with and without its sorted copy) == search from the image
+    flat = labels.reshape(-1)
+    assert torch.equal(eng.encode(blocks, cb, mode=1, sorted=eng.sort_blocks(blocks)).reshape(-1), flat)
+    assert torch.equal(eng.encode(blocks, cb, mode=1).reshape(-1), flat)
+    del blocks
+    # decode of the whole batch: every image equals its own decode; bit stream round trip of 2^27 labels
+    dec = eng.decode(flat.view(n_img * (side // 4), side // 4), cb, 4, 4, 1).view(n_img, side, side)
+    for i in (0, 300, n_img - 1):
+        assert torch.equal(dec[i], eng.decode(labels[i].view(side // 4, side // 4), cb, 4, 4, 1).view(side, side))
+    packed = eng.pack_labels(flat, 256)
+    assert torch.equal(eng.unpack_labels(packed, flat.numel(), 256), flat)
