@@ -56,7 +56,8 @@ def _check_sorted(buf, blocks):
         assert np.all(np.diff(rows[w0: w0 + n].astype(np.int64).sum(1) >> shift) >= 0)
 
 
-@pytest.mark.parametrize("N,d", [(700, 16), (8192 + 300, 16), (3000, 4), (2500, 27)])
+@pytest.mark.parametrize("N,d", [(700, 16), (8192 + 300, 16), (3000, 4), (2500, 27), (8192 + 2300, 48), (4100, 32), (5, 48),
+                                 (2049, 48), (900, 64)])
 def test_emu_window_sort(eng, N, d):
     rng = np.random.default_rng(N + d)
     blocks = np.clip(rng.integers(0, 200, size=(N, 1)) + rng.integers(0, 56, size=(N, d)), 0, 255).astype(np.uint8)
@@ -238,7 +239,7 @@ def test_emu_pruned_fixup(eng, oracle, K, d, N, use_sorted):
 
 @pytest.mark.parametrize("shape,bh,bw,pad", [((64, 96, 1), 4, 4, 0), ((37, 53, 1), 4, 4, 0), ((37, 53, 1), 4, 4, 1), ((30, 22, 3), 2, 2, 0),
                                              ((19, 27, 1), 2, 2, 1), ((33, 20, 3), 4, 4, 0), ((21, 50, 1), 2, 4, 0), ((40, 36, 2), 3, 3, 0),
-                                             ((400, 400, 1), 4, 4, 0)])
+                                             ((400, 400, 1), 4, 4, 0), ((198, 202, 3), 4, 4, 0), ((198, 202, 3), 4, 4, 1), ((260, 128, 1), 8, 4, 0)])
 def test_emu_sort_image_equals_extract_then_sort(eng, oracle, shape, bh, bw, pad):
     """Image -> sorted rows in one pass: a valid window-sorted copy of exactly the block matrix that
     block extraction gives (word and byte paths, both pad modes, ragged sizes, more than one window)."""

@@ -35,6 +35,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 #include <stdarg.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -1125,32 +1126,62 @@ __global__ __launch_bounds__(1024) void k_window_sort(const SRC src, int64_t N, 
         for (int w = tid; w < dw; w += T) s_woff[w] = src.word_off(w);
     __syncthreads();
     uint32_t bucket[PER], rank[PER];
+    if (WORDS && direct) {
+        // the PER vectors of a thread side by side: one trip of the word loop has PER independent loads in flight
+        // (a vector that needs padding, or lies beyond the window, reads the image's first word instead and is
+        // summed through src.word afterwards)
+        uint32_t base[PER], sum[PER];
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const int li = j * T + tid;
-        bucket[j] = 0;
-        rank[j] = 0;
-        if (li < count) {
-            uint32_t sum = 0;
-            if (WORDS) {
+        for (int j = 0; j < PER; ++j) {
+            const int li = j * T + tid;
+            uint32_t b = 0xffffffffu;
+            if (li < count) {
                 bool inside = false;
-                uint32_t base = 0xffffffffu;
-                if (direct) {
-                    base = src.vec_base(w0 + li, inside);
-                    base = inside ? base : 0xffffffffu;
-                    s_base[li] = base;
-                }
-                if (inside) {
-                    for (int w = 0; w < dw; ++w)
-                        sum = __builtin_amdgcn_sad_u8(*reinterpret_cast<const uint32_t *>(org + base + s_woff[w]), 0u, sum);
-                } else {
-                    for (int w = 0; w < dw; ++w) sum = __builtin_amdgcn_sad_u8(src.word(w0 + li, w), 0u, sum);
-                }
-            } else {
-                for (int e = 0; e < d; ++e) sum += src.byte(w0 + li, e);
+                b = src.vec_base(w0 + li, inside);
+                b = inside ? b : 0xffffffffu;
+                s_base[li] = b;
             }
-            bucket[j] = sum >> bshift;
-            rank[j] = atomicAdd(&s_cnt[bucket[j]], 1u);
+            base[j] = b;
+            sum[j] = 0;
+        }
+        for (int w = 0; w < dw; ++w) {
+            const uint32_t off = s_woff[w];
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const uint32_t at = base[j] != 0xffffffffu ? base[j] + off : 0u;
+                sum[j] = __builtin_amdgcn_sad_u8(*reinterpret_cast<const uint32_t *>(org + at), 0u, sum[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int li = j * T + tid;
+            bucket[j] = 0;
+            rank[j] = 0;
+            if (li < count) {
+                if (base[j] == 0xffffffffu) {
+                    sum[j] = 0;
+                    for (int w = 0; w < dw; ++w) sum[j] = __builtin_amdgcn_sad_u8(src.word(w0 + li, w), 0u, sum[j]);
+                }
+                bucket[j] = sum[j] >> bshift;
+                rank[j] = atomicAdd(&s_cnt[bucket[j]], 1u);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int li = j * T + tid;
+            bucket[j] = 0;
+            rank[j] = 0;
+            if (li < count) {
+                uint32_t sum = 0;
+                if (WORDS) {
+                    for (int w = 0; w < dw; ++w) sum = __builtin_amdgcn_sad_u8(src.word(w0 + li, w), 0u, sum);
+                } else {
+                    for (int e = 0; e < d; ++e) sum += src.byte(w0 + li, e);
+                }
+                bucket[j] = sum >> bshift;
+                rank[j] = atomicAdd(&s_cnt[bucket[j]], 1u);
+            }
         }
     }
     __syncthreads();
@@ -1179,21 +1210,44 @@ __global__ __launch_bounds__(1024) void k_window_sort(const SRC src, int64_t N, 
     __syncthreads();
     for (int i = tid; i < count; i += T) perm[w0 + i] = s_inv[i];
     if (WORDS) {
+        // U words per thread and trip: their slot look-ups, their loads and their stores in groups, so that U
+        // loads are in flight at once (one word per trip leaves the copy waiting on a chain of LDS and cache
+        // latencies per word)
         uint32_t *out = reinterpret_cast<uint32_t *>(rows) + (size_t)w0 * dw;
         const int total = count * dw;
-        if (direct) {
-            const unsigned long long magic = ((1ull << 32) + (unsigned)dw - 1ull) / (unsigned)dw;   // i / dw for i * dw < 2^32
-            for (int i = tid; i < total; i += T) {
-                const int slot = (int)(((unsigned long long)(unsigned)i * magic) >> 32), w = i - slot * dw;
-                const int li = s_inv[slot];
-                const uint32_t base = s_base[li];
-                out[i] = base != 0xffffffffu ? *reinterpret_cast<const uint32_t *>(org + base + s_woff[w])
-                                             : src.word(w0 + (int64_t)li, w);
+        constexpr int U = 8;
+        const unsigned long long magic = ((1ull << 32) + (unsigned)dw - 1ull) / (unsigned)dw;   // i / dw for i * dw < 2^32
+        for (int i0 = tid; i0 < total; i0 += T * U) {
+            uint32_t val[U];
+            int li[U], ww[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * T;
+                const int ic = i < total ? i : 0;
+                const int slot = (int)(((unsigned long long)(unsigned)ic * magic) >> 32);
+                ww[u] = ic - slot * dw;
+                li[u] = s_inv[slot];
             }
-        } else {
-            for (int i = tid; i < total; i += T) {
-                const int slot = i / dw, w = i - slot * dw;
-                out[i] = src.word(w0 + (int64_t)s_inv[slot], w);
+            if (direct) {
+                uint32_t base[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) base[u] = s_base[li[u]];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t at = base[u] != 0xffffffffu ? base[u] + s_woff[ww[u]] : 0u;
+                    val[u] = *reinterpret_cast<const uint32_t *>(org + at);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (base[u] == 0xffffffffu) val[u] = src.word(w0 + (int64_t)li[u], ww[u]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) val[u] = src.word(w0 + (int64_t)li[u], ww[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * T;
+                if (i < total) out[i] = val[u];
             }
         }
     } else {
@@ -1331,6 +1385,196 @@ __global__ __launch_bounds__(1024) void k_window_sort_lds(const SRC src, int64_t
         for (int j = 0; j < PER; ++j)
 #pragma unroll
             for (int w = 0; w < DW; ++w) keep[j][w] = nxt[j][w];
+    }
+}
+
+// The same sort for rows of 5 .. 12 words (RGB 4x4 blocks: 48 bytes).  A window of such rows (up to 384 KB)
+// is beyond the LDS, and copying it in output order straight from the source gathers 12-byte pieces out of
+// 128-byte cache lines: the caches move ten times the bytes they deliver.  Here every thread keeps its 16 rows
+// in registers from one coalesced read (512 threads, 16 * DW registers of rows), and the window leaves through
+// the LDS in chunks of SORT_CHUNK sorted slots: the rows of a chunk are placed at their sorted positions and
+// written out in order with 16-byte stores.  Dynamic LDS: SORT_CHUNK * DW words.  (Reading an RGB pixel row
+// of a block with one 12-byte load was measured slower: the register triples it needs push rows into scratch.)
+constexpr int SORT_CHUNK = 2048;
+template <int DW, class SRC>
+__global__ __launch_bounds__(512) void k_window_sort_regs(const SRC src, int64_t N, int bshift,
+                                                          uint32_t *__restrict__ rows, uint16_t *__restrict__ perm,
+                                                          SortedHeader *__restrict__ shdr) {
+    constexpr int T = 512;
+    constexpr int PER = SORT_WIN / T;                       // vectors per thread
+    constexpr int BPT = SORT_BUCKETS / T;                   // buckets per thread in the scan
+    static_assert(SORT_WIN % T == 0 && SORT_BUCKETS % T == 0 && SORT_WIN % SORT_CHUNK == 0 && SORT_BUCKETS <= 65536 &&
+                  SORT_WIN <= 65536, "window sort geometry");
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        shdr->magic = SORTED_MAGIC;
+        shdr->d = (uint32_t)(4 * DW);
+        shdr->N = (unsigned long long)N;
+    }
+    extern __shared__ __align__(16) uint32_t s_chunk[];
+    __shared__ uint32_t s_cnt[SORT_BUCKETS];
+    __shared__ uint32_t s_wsum[T / WAVE];
+    __shared__ uint32_t s_woff[DW];
+    __shared__ __align__(16) uint16_t s_perm[SORT_WIN];     // sorted slot -> origin (before that: sums of padded vectors)
+    __shared__ uint16_t s_padslot[SORT_WIN];                // sorted slot of each vector that needs padding
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
+    const int64_t w0 = (int64_t)blockIdx.x * SORT_WIN;
+    const int count = (int)((N - w0) < SORT_WIN ? (N - w0) : SORT_WIN);      // vectors in this window (>= 1)
+    // The image source is read by direct addressing only (the host sends other images to k_window_sort); the
+    // few vectors that need padding never enter the registers: their sums and, later, their rows go through
+    // src.word in one rolled loop each (what they need from one phase to the next waits in the LDS), so that
+    // `keep` and `slot` are only ever indexed by constants and the padding code exists once.
+    constexpr bool DIRECT = !std::is_same<SRC, SrcBlocks>::value;
+    const uint8_t *org = src.origin();
+    for (int i = tid; i < SORT_BUCKETS; i += T) s_cnt[i] = 0u;
+    if (DIRECT && tid < DW) s_woff[tid] = src.word_off(tid);
+    __syncthreads();
+    uint32_t keep[PER][DW];
+    uint32_t padmask = 0;                                   // bit j: vector j of this thread needs padding
+    if constexpr (DIRECT) {
+        constexpr int GRP = PER / 4;                        // (in four groups: fewer addresses alive beside the rows)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            uint32_t base[GRP];
+#pragma unroll
+            for (int jj = 0; jj < GRP; ++jj) {
+                const int j = h * GRP + jj;
+                const int li = j * T + tid;
+                uint32_t b = 0u;                            // beyond the window: the image's first block, unused
+                if (li < count) {
+                    bool inside = false;
+                    b = src.vec_base(w0 + li, inside);
+                    if (!inside) {
+                        b = 0u;
+                        padmask |= 1u << j;
+                    }
+                }
+                base[jj] = b;
+            }
+#pragma unroll
+            for (int w = 0; w < DW; ++w) {
+                const uint32_t off = s_woff[w];
+#pragma unroll
+                for (int jj = 0; jj < GRP; ++jj)
+                    keep[h * GRP + jj][w] = *reinterpret_cast<const uint32_t *>(org + (uint32_t)(base[jj] + off));
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int li = j * T + tid;
+            const int lc = li < count ? li : count - 1;     // clamped: loads stay in bounds
+            src.template row_words<DW>(w0 + lc, keep[j]);
+        }
+    }
+    if (DIRECT && padmask != 0u) {
+#pragma nounroll
+        for (int j = 0; j < PER; ++j) {
+            if (padmask >> j & 1u) {
+                const int li = j * T + tid;
+                uint32_t sum = 0;
+                for (int w = 0; w < DW; ++w) sum = __builtin_amdgcn_sad_u8(src.word(w0 + li, w), 0u, sum);
+                s_perm[li] = (uint16_t)sum;                 // <= 255 * 4 * DW; read back by this thread below
+            }
+        }
+    }
+    uint32_t slot[PER];                                     // first bucket | rank in the bucket << 16, then the sorted position
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int li = j * T + tid;
+        uint32_t sum = 0;
+#pragma unroll
+        for (int w = 0; w < DW; ++w) sum = __builtin_amdgcn_sad_u8(keep[j][w], 0u, sum);
+        if (DIRECT && (padmask >> j & 1u)) sum = s_perm[li];
+        const uint32_t bucket = sum >> bshift;              // < SORT_BUCKETS
+        slot[j] = bucket | (li < count ? atomicAdd(&s_cnt[bucket], 1u) : 0u) << 16;
+    }
+    __syncthreads();
+    // exclusive scan of the bucket counts: BPT buckets per thread, wave scan, then the wave totals
+    uint32_t c[BPT], incl = 0;
+#pragma unroll
+    for (int b = 0; b < BPT; ++b) {
+        c[b] = s_cnt[BPT * tid + b];
+        incl += c[b];
+    }
+    const uint32_t mine = incl;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, WAVE);
+        if (lane >= off) incl += o;
+    }
+    if (lane == WAVE - 1) s_wsum[wv] = incl;
+    __syncthreads();
+    uint32_t run = incl - mine;
+    for (int i = 0; i < wv; ++i) run += s_wsum[i];
+#pragma unroll
+    for (int b = 0; b < BPT; ++b) {
+        s_cnt[BPT * tid + b] = run;
+        run += c[b];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int li = j * T + tid;
+        if (li < count) {
+            slot[j] = s_cnt[slot[j] & 0xffffu] + (slot[j] >> 16);           // < count
+            s_perm[slot[j]] = (uint16_t)li;
+            if (DIRECT && (padmask >> j & 1u)) {
+                s_padslot[li] = (uint16_t)slot[j];
+                slot[j] = 0xffffffffu;                      // placed by the padding loop of its chunk
+            }
+        } else {
+            slot[j] = 0xffffffffu;                          // in no chunk
+        }
+    }
+    for (int cs = 0; cs < count; cs += SORT_CHUNK) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const uint32_t rel = slot[j] - (uint32_t)cs;
+            if (rel < (uint32_t)SORT_CHUNK) {
+                if constexpr (DW % 4 == 0) {
+                    uint4 *dst = reinterpret_cast<uint4 *>(s_chunk + (size_t)rel * DW);
+#pragma unroll
+                    for (int q = 0; q < DW / 4; ++q)
+                        dst[q] = make_uint4(keep[j][4 * q], keep[j][4 * q + 1], keep[j][4 * q + 2], keep[j][4 * q + 3]);
+                } else {
+#pragma unroll
+                    for (int w = 0; w < DW; ++w) s_chunk[(size_t)rel * DW + w] = keep[j][w];
+                }
+            }
+        }
+        if (DIRECT && padmask != 0u) {
+#pragma nounroll
+            for (int j = 0; j < PER; ++j) {
+                if (padmask >> j & 1u) {
+                    const int li = j * T + tid;
+                    const uint32_t rel = (uint32_t)s_padslot[li] - (uint32_t)cs;
+                    if (rel < (uint32_t)SORT_CHUNK)
+                        for (int w = 0; w < DW; ++w) s_chunk[(size_t)rel * DW + w] = src.word(w0 + li, w);
+                }
+            }
+        }
+        __syncthreads();                                    // (the first trip also completes s_perm)
+        const int n = (count - cs) < SORT_CHUNK ? (count - cs) : SORT_CHUNK;
+        const int words = n * DW;
+        uint32_t *orow = rows + ((size_t)w0 + (size_t)cs) * DW;     // 16-byte aligned: w0 and cs are multiples of 4 rows
+        if ((words & 3) == 0) {
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(s_chunk);
+            uint4 *o4 = reinterpret_cast<uint4 *>(orow);
+            for (int i = tid; i < words / 4; i += T) o4[i] = s4[i];
+        } else {
+            for (int i = tid; i < words; i += T) orow[i] = s_chunk[i];
+        }
+        if (cs == 0) {
+            uint16_t *operm = perm + w0;
+            if ((count & 7) == 0 && (reinterpret_cast<uintptr_t>(operm) & 15) == 0) {
+                const uint4 *sp = reinterpret_cast<const uint4 *>(s_perm);
+                uint4 *op = reinterpret_cast<uint4 *>(operm);
+                for (int i = tid; i < count / 8; i += T) op[i] = sp[i];
+            } else {
+                for (int i = tid; i < count; i += T) operm[i] = s_perm[i];
+            }
+        }
+        __syncthreads();                                    // the chunk is free for the next slots
     }
 }
 
@@ -3487,6 +3731,13 @@ int run_numpy_sum(const double *v, int64_t N, double *chunk_sums, double *out, h
     return VQ_OK;
 }
 
+// k_window_sort_regs reads an image by direct addressing only: 32-bit byte offsets, rows and block segments of
+// whole aligned words, and at least one whole block row and column (its idle lanes read the first block).
+bool sort_in_registers_ok(const SrcBlocks &) { return true; }
+bool sort_in_registers_ok(const SrcImage &s) {
+    return s.fast32 != 0 && s.words_ok != 0 && (s.seg & 3u) == 0 && s.H >= s.bh && s.W >= s.bw;
+}
+
 // Fills `sorted` (rows, origins, header) from a vector source.  row_words_ok: rows are whole words the
 // source can deliver aligned; rows of one to four such words are staged in LDS and leave in order.
 template <class SRC>
@@ -3527,6 +3778,19 @@ int run_sort(const SRC &src, bool row_words_ok, int64_t N, int d, void *sorted, 
             default: VQ_LAUNCH_SORT(4); break;
         }
 #undef VQ_LAUNCH_SORT
+    } else if (row_words_ok && (d == 48 || d == 32) && sort_in_registers_ok(src) &&
+               (size_t)SORT_CHUNK * d + (size_t)SORT_WIN * 4 + (SORT_BUCKETS + 64) * 4 + 256 <= di.lds_per_block) {
+        const size_t lds = (size_t)SORT_CHUNK * d;
+        uint32_t *r32 = reinterpret_cast<uint32_t *>(rows);
+#define VQ_LAUNCH_SORT_REGS(DW)                                                                                     \
+    do {                                                                                                            \
+        auto kern = k_window_sort_regs<DW, SRC>;                                                                    \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, src, N, bshift, r32, perm, shdr);                  \
+    } while (0)
+        if (d == 48) VQ_LAUNCH_SORT_REGS(12);
+        else VQ_LAUNCH_SORT_REGS(8);
+#undef VQ_LAUNCH_SORT_REGS
     } else if (row_words_ok) {
         hipLaunchKernelGGL((k_window_sort<SRC, true>), dim3(grid), dim3(1024), 0, st, src, N, d, bshift, rows, perm, shdr);
     } else {
