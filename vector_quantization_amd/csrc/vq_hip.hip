@@ -1099,7 +1099,7 @@ struct SrcImage {
 template <class SRC, bool WORDS>
 __global__ __launch_bounds__(1024) void k_window_sort(const SRC src, int64_t N, int d, int bshift,
                                                       uint8_t *__restrict__ rows, uint16_t *__restrict__ perm,
-                                                      SortedHeader *__restrict__ shdr) {
+                                                      SortedHeader *__restrict__ shdr, int copy_rows) {
     constexpr int T = 1024;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         shdr->magic = SORTED_MAGIC;
@@ -1144,7 +1144,8 @@ __global__ __launch_bounds__(1024) void k_window_sort(const SRC src, int64_t N, 
             base[j] = b;
             sum[j] = 0;
         }
-        for (int w = 0; w < dw; ++w) {
+#pragma unroll 4
+        for (int w = 0; w < dw; ++w) {                      // (four trips' loads in flight: long rows wait on latency)
             const uint32_t off = s_woff[w];
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
@@ -1209,6 +1210,7 @@ __global__ __launch_bounds__(1024) void k_window_sort(const SRC src, int64_t N, 
     }
     __syncthreads();
     for (int i = tid; i < count; i += T) perm[w0 + i] = s_inv[i];
+    if (!copy_rows) return;                                 // (uniform) k_sort_gather copies the rows
     if (WORDS) {
         // U words per thread and trip: their slot look-ups, their loads and their stores in groups, so that U
         // loads are in flight at once (one word per trip leaves the copy waiting on a chain of LDS and cache
@@ -1256,6 +1258,86 @@ __global__ __launch_bounds__(1024) void k_window_sort(const SRC src, int64_t N, 
         for (int i = tid; i < total; i += T) {
             const int slot = i / d, e = i - slot * d;
             out[i] = (uint8_t)src.byte(w0 + (int64_t)s_inv[slot], e);
+        }
+    }
+}
+
+// Second launch of the generic window sort when the windows are too few to fill the chip (a workgroup per window
+// leaves most compute units idle and the copy waits on one unit's load latency): `parts` workgroups per window copy
+// the rows in output order from the origin map that k_window_sort (copy_rows = 0) left in `perm`.
+template <class SRC, bool WORDS>
+__global__ __launch_bounds__(1024) void k_sort_gather(const SRC src, int64_t N, int d, int parts,
+                                                      uint8_t *__restrict__ rows, const uint16_t *__restrict__ perm) {
+    constexpr int T = 1024;
+    __shared__ uint16_t s_li[SORT_WIN];                     // slot - s0 -> position in the window it came from
+    __shared__ uint32_t s_base[WORDS ? SORT_WIN : 1];       // slot - s0 -> first byte (0xffffffff: needs padding)
+    __shared__ uint32_t s_woff[WORDS ? MAX_D_FAST / 4 : 1];
+    const int tid = threadIdx.x;
+    const int64_t win = (int64_t)(blockIdx.x / (unsigned)parts);
+    const int part = (int)(blockIdx.x % (unsigned)parts);
+    const int64_t w0 = win * SORT_WIN;
+    const int count = (int)((N - w0) < SORT_WIN ? (N - w0) : SORT_WIN);
+    const int per = (count + parts - 1) / parts;            // sorted slots per part
+    const int s0 = part * per < count ? part * per : count;
+    const int s1 = s0 + per < count ? s0 + per : count;
+    const int dw = d >> 2;
+    const bool direct = WORDS && src.fast_words();
+    const uint8_t *org = src.origin();
+    for (int sl = s0 + tid; sl < s1; sl += T) {
+        const int li = perm[w0 + sl];
+        s_li[sl - s0] = (uint16_t)li;
+        if (WORDS && direct) {
+            bool inside = false;
+            const uint32_t b = src.vec_base(w0 + li, inside);
+            s_base[sl - s0] = inside ? b : 0xffffffffu;
+        }
+    }
+    if (WORDS && direct)
+        for (int w = tid; w < dw; w += T) s_woff[w] = src.word_off(w);
+    __syncthreads();
+    if (WORDS) {
+        uint32_t *out = reinterpret_cast<uint32_t *>(rows) + ((size_t)w0 + (size_t)s0) * dw;
+        const int total = (s1 - s0) * dw;
+        constexpr int U = 8;
+        const unsigned long long magic = ((1ull << 32) + (unsigned)dw - 1ull) / (unsigned)dw;   // i / dw for i * dw < 2^32
+        for (int i0 = tid; i0 < total; i0 += T * U) {
+            uint32_t val[U];
+            int rel[U], ww[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * T;
+                const int ic = i < total ? i : 0;
+                rel[u] = (int)(((unsigned long long)(unsigned)ic * magic) >> 32);
+                ww[u] = ic - rel[u] * dw;
+            }
+            if (direct) {
+                uint32_t base[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) base[u] = s_base[rel[u]];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t at = base[u] != 0xffffffffu ? base[u] + s_woff[ww[u]] : 0u;
+                    val[u] = *reinterpret_cast<const uint32_t *>(org + at);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (base[u] == 0xffffffffu) val[u] = src.word(w0 + (int64_t)s_li[rel[u]], ww[u]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) val[u] = src.word(w0 + (int64_t)s_li[rel[u]], ww[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * T;
+                if (i < total) out[i] = val[u];
+            }
+        }
+    } else {
+        uint8_t *out = rows + ((size_t)w0 + (size_t)s0) * d;
+        const int total = (s1 - s0) * d;
+        for (int i = tid; i < total; i += T) {
+            const int rel = i / d, e = i - rel * d;
+            out[i] = (uint8_t)src.byte(w0 + (int64_t)s_li[rel], e);
         }
     }
 }
@@ -3791,10 +3873,23 @@ int run_sort(const SRC &src, bool row_words_ok, int64_t N, int d, void *sorted, 
         if (d == 48) VQ_LAUNCH_SORT_REGS(12);
         else VQ_LAUNCH_SORT_REGS(8);
 #undef VQ_LAUNCH_SORT_REGS
-    } else if (row_words_ok) {
-        hipLaunchKernelGGL((k_window_sort<SRC, true>), dim3(grid), dim3(1024), 0, st, src, N, d, bshift, rows, perm, shdr);
     } else {
-        hipLaunchKernelGGL((k_window_sort<SRC, false>), dim3(grid), dim3(1024), 0, st, src, N, d, bshift, rows, perm, shdr);
+        // few windows: the rows are copied by a second launch with several workgroups per window
+        int parts = 1;
+        if (grid * 4 <= di.cus) parts = di.cus / grid < 16 ? di.cus / grid : 16;   // (two parts per window: measured no gain)
+        if (row_words_ok)
+            hipLaunchKernelGGL((k_window_sort<SRC, true>), dim3(grid), dim3(1024), 0, st, src, N, d, bshift, rows, perm, shdr,
+                               parts == 1 ? 1 : 0);
+        else
+            hipLaunchKernelGGL((k_window_sort<SRC, false>), dim3(grid), dim3(1024), 0, st, src, N, d, bshift, rows, perm, shdr,
+                               parts == 1 ? 1 : 0);
+        if (parts > 1) {
+            LAUNCH_CHECK("k_window_sort");
+            if (row_words_ok)
+                hipLaunchKernelGGL((k_sort_gather<SRC, true>), dim3(grid * parts), dim3(1024), 0, st, src, N, d, parts, rows, perm);
+            else
+                hipLaunchKernelGGL((k_sort_gather<SRC, false>), dim3(grid * parts), dim3(1024), 0, st, src, N, d, parts, rows, perm);
+        }
     }
     LAUNCH_CHECK("k_window_sort");
     sorted_register(sorted, N, d, sorted_bytes);
