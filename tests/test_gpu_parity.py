@@ -308,7 +308,7 @@ def _sorted_parts(buf, N, d):
 
 
 @pytest.mark.parametrize("N,d", [(1, 16), (100, 16), (8192, 16), (8193, 16), (30000, 16), (20001, 4), (9000, 27), (17000, 32),
-                                 (8500, 48)])
+                                 (8500, 48), (3, 48), (70000, 48), (5000, 192), (40000, 64), (600000, 64)])
 def test_sort_blocks_is_a_windowed_permutation(eng, N, d):
     rng = np.random.default_rng(N + d)
     base = rng.integers(0, 200, size=(N, 1))
@@ -643,7 +643,9 @@ def test_sort_image_golden(eng, train_case):
 
 
 @pytest.mark.parametrize("shape,bh,bw", [((7, 5, 3), 2, 2), ((33, 17, 1), 4, 4), ((64, 64, 3), 8, 8), ((9, 9, 1), 3, 3),
-                                         ((130, 67, 3), 3, 5), ((16, 20, 2), 4, 2), ((515, 770, 1), 4, 4), ((300, 301, 1), 2, 2)])
+                                         ((130, 67, 3), 3, 5), ((16, 20, 2), 4, 2), ((515, 770, 1), 4, 4), ((300, 301, 1), 2, 2),
+                                         ((398, 402, 3), 4, 4), ((37, 44, 3), 4, 4), ((3, 2, 3), 4, 4), ((1030, 516, 1), 4, 8),
+                                         ((250, 260, 3), 8, 8)])
 @pytest.mark.parametrize("pad_mode", [0, 1])
 def test_sort_image_ragged(eng, oracle, shape, bh, bw, pad_mode):
     rng = np.random.default_rng(hash((shape, bh, bw)) & 0xffff)
