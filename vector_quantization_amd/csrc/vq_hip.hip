@@ -1099,7 +1099,7 @@ struct SrcImage {
 template <class SRC, bool WORDS>
 __global__ __launch_bounds__(1024) void k_window_sort(const SRC src, int64_t N, int d, int bshift,
                                                       uint8_t *__restrict__ rows, uint16_t *__restrict__ perm,
-                                                      SortedHeader *__restrict__ shdr, int copy_rows) {
+                                                      SortedHeader *__restrict__ shdr, int copy_rows, int sums_given) {
     constexpr int T = 1024;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         shdr->magic = SORTED_MAGIC;
@@ -1126,7 +1126,24 @@ __global__ __launch_bounds__(1024) void k_window_sort(const SRC src, int64_t N, 
         for (int w = tid; w < dw; w += T) s_woff[w] = src.word_off(w);
     __syncthreads();
     uint32_t bucket[PER], rank[PER];
-    if (WORDS && direct) {
+    if (sums_given) {
+        // (uniform) k_sort_sums left every vector's element sum in its `perm` entry; the origin map replaces them below
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int li = j * T + tid;
+            bucket[j] = 0;
+            rank[j] = 0;
+            if (li < count) {
+                if (WORDS && direct) {
+                    bool inside = false;
+                    const uint32_t b = src.vec_base(w0 + li, inside);
+                    s_base[li] = inside ? b : 0xffffffffu;
+                }
+                bucket[j] = (uint32_t)perm[w0 + li] >> bshift;
+                rank[j] = atomicAdd(&s_cnt[bucket[j]], 1u);
+            }
+        }
+    } else if (WORDS && direct) {
         // the PER vectors of a thread side by side: one trip of the word loop has PER independent loads in flight
         // (a vector that needs padding, or lies beyond the window, reads the image's first word instead and is
         // summed through src.word afterwards)
@@ -1259,6 +1276,46 @@ __global__ __launch_bounds__(1024) void k_window_sort(const SRC src, int64_t N, 
             const int slot = i / d, e = i - slot * d;
             out[i] = (uint8_t)src.byte(w0 + (int64_t)s_inv[slot], e);
         }
+    }
+}
+
+// First launch of the generic window sort when the windows are too few to fill the chip: the element sums of the
+// vectors, `parts` workgroups per window, left in the vectors' `perm` entries (a sum is at most 255 * 192 < 2^16)
+// for k_window_sort (sums_given = 1), which ranks them and overwrites the entries with the origin map.
+template <class SRC, bool WORDS>
+__global__ __launch_bounds__(1024) void k_sort_sums(const SRC src, int64_t N, int d, int parts, uint16_t *__restrict__ perm) {
+    constexpr int T = 1024;
+    __shared__ uint32_t s_woff[WORDS ? MAX_D_FAST / 4 : 1];
+    const int tid = threadIdx.x;
+    const int64_t win = (int64_t)(blockIdx.x / (unsigned)parts);
+    const int part = (int)(blockIdx.x % (unsigned)parts);
+    const int64_t w0 = win * SORT_WIN;
+    const int count = (int)((N - w0) < SORT_WIN ? (N - w0) : SORT_WIN);
+    const int per = (count + parts - 1) / parts;            // vectors per part
+    const int l0 = part * per < count ? part * per : count;
+    const int l1 = l0 + per < count ? l0 + per : count;
+    const int dw = d >> 2;
+    const bool direct = WORDS && src.fast_words();
+    const uint8_t *org = src.origin();
+    if (WORDS && direct)
+        for (int w = tid; w < dw; w += T) s_woff[w] = src.word_off(w);
+    __syncthreads();
+    for (int li = l0 + tid; li < l1; li += T) {
+        uint32_t sum = 0;
+        if (WORDS) {
+            bool inside = false;
+            const uint32_t base = direct ? src.vec_base(w0 + li, inside) : 0u;
+            if (inside) {
+#pragma unroll 8
+                for (int w = 0; w < dw; ++w)
+                    sum = __builtin_amdgcn_sad_u8(*reinterpret_cast<const uint32_t *>(org + (uint32_t)(base + s_woff[w])), 0u, sum);
+            } else {
+                for (int w = 0; w < dw; ++w) sum = __builtin_amdgcn_sad_u8(src.word(w0 + li, w), 0u, sum);
+            }
+        } else {
+            for (int e = 0; e < d; ++e) sum += src.byte(w0 + li, e);
+        }
+        perm[w0 + li] = (uint16_t)sum;
     }
 }
 
@@ -3877,12 +3934,20 @@ int run_sort(const SRC &src, bool row_words_ok, int64_t N, int d, void *sorted, 
         // few windows: the rows are copied by a second launch with several workgroups per window
         int parts = 1;
         if (grid * 4 <= di.cus) parts = di.cus / grid < 16 ? di.cus / grid : 16;   // (two parts per window: measured no gain)
+        static_assert(255 * MAX_D_FAST < 65536, "element sums travel in 16-bit entries");
+        if (parts > 1) {
+            if (row_words_ok)
+                hipLaunchKernelGGL((k_sort_sums<SRC, true>), dim3(grid * parts), dim3(1024), 0, st, src, N, d, parts, perm);
+            else
+                hipLaunchKernelGGL((k_sort_sums<SRC, false>), dim3(grid * parts), dim3(1024), 0, st, src, N, d, parts, perm);
+            LAUNCH_CHECK("k_sort_sums");
+        }
         if (row_words_ok)
             hipLaunchKernelGGL((k_window_sort<SRC, true>), dim3(grid), dim3(1024), 0, st, src, N, d, bshift, rows, perm, shdr,
-                               parts == 1 ? 1 : 0);
+                               parts == 1 ? 1 : 0, parts == 1 ? 0 : 1);
         else
             hipLaunchKernelGGL((k_window_sort<SRC, false>), dim3(grid), dim3(1024), 0, st, src, N, d, bshift, rows, perm, shdr,
-                               parts == 1 ? 1 : 0);
+                               parts == 1 ? 1 : 0, parts == 1 ? 0 : 1);
         if (parts > 1) {
             LAUNCH_CHECK("k_window_sort");
             if (row_words_ok)
