@@ -176,6 +176,10 @@ int vq_lbg_accum(const uint8_t *blocks, const void *sorted, size_t sorted_bytes,
  * A negative threshold never converges (forced iteration counts).  Consecutive iterations of a stage that use
  * the same ws and state, with no other entry point given that ws in between, skip re-zeroing the tables of ws
  * (the previous iteration leaves them zeroed); any other call sequence is detected and costs one extra fill. */
+/* 1 when vq_lbg_iterate in VQ_MODE_FAST with a `sorted` buffer runs this (K, d) as one fused pass (search and
+ * accumulation in one kernel): labels may then be null (none are written, which saves their stores during
+ * training) and min_dist is scratch whose contents are unspecified afterwards.  0: labels is required. */
+int vq_lbg_pass_fused(int K, int d);
 size_t vq_lbg_state_bytes(int max_iterations);
 int vq_lbg_stage_begin(void *state, size_t state_bytes, int max_iterations, void *stream);
 int vq_lbg_iterate(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d, double *cb, int K,

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Builds tests/emu/_build/libvqemu.so: the kernels and the C ABI of
 vector_quantization_amd/csrc/vq_hip.hip compiled for the host against tests/emu/hip/hip_runtime.h.
-TEST INFRASTRUCTURE ONLY.  The source is used as it is, apart from three textual substitutions a
+TEST INFRASTRUCTURE ONLY.  The source is used as it is, apart from a few textual substitutions a
 host compiler needs (each checked to match, so that a change of the source is noticed here):
 dynamic LDS declarations become pointers into the emulated LDS, and the three kinds of inline
 gfx950 assembly become their C++ meaning (the LDS wait of a lockstep wave becomes a wave rendezvous)."""
@@ -29,9 +29,9 @@ thread_local emu::Idx threadIdx, blockIdx, blockDim, gridDim;
 def transform(text):
     n_total = 0
 
-    def sub(pattern, repl, text, expect_min):
+    def sub(pattern, repl, text, expect_min, flags=0):
         nonlocal n_total
-        out, n = re.subn(pattern, repl, text)
+        out, n = re.subn(pattern, repl, text, flags=flags)
         if n < expect_min:
             raise SystemExit(f"emu build: pattern {pattern!r} matched {n} times, expected at least {expect_min}")
         n_total += n
@@ -43,8 +43,10 @@ def transform(text):
     # v_med3_u32: the median of three
     text = sub(r'asm\("v_med3_u32 %0, %1, %2, %3" : "=v"\(r\) : "v"\(a\), "v"\(b\), "v"\(c\)\);',
                "r = std::max(std::min(a, b), std::min(std::max(a, b), c));", text, 1)
+    # scalar loads issued ahead of their use: the source carries its own host form next to the gfx950 one
+    text = sub(r"#ifndef VQ_HOST_EMULATION\n.*?\n#else\n(.*?)\n#endif  // VQ_HOST_EMULATION\n", r"\1\n", text, 1, flags=re.S)
     # register-class hints and LDS waits have no host meaning
-    text = sub(r'asm volatile\("" : "\+v"\(([a-z_]+)\)\);', r"(void)\1;", text, 2)
+    text = sub(r'asm volatile\("" : "\+v"\(([a-z0-9_]+)\)\);', r"(void)\1;", text, 2)
     # "wait for my LDS operations" orders LDS traffic between the lanes of a wave that runs in lockstep;
     # the emulated lanes are free-running threads, so it becomes a rendezvous of the wave
     text = sub(r'asm volatile\("s_waitcnt lgkmcnt\(0\)" ::: "memory"\);', "emu::wave().bar.wait();", text, 2)

@@ -185,11 +185,12 @@ inline uint32_t emu_sad_u8(uint32_t a, uint32_t b, uint32_t acc) {
     for (int i = 0; i < 4; ++i) acc += (uint32_t)std::abs((int)((a >> (8 * i)) & 0xff) - (int)((b >> (8 * i)) & 0xff));
     return acc;
 }
-inline uint32_t emu_perm(uint32_t s0, uint32_t s1, uint32_t sel) {     // v_perm_b32, selector values 0..7 only
+inline uint32_t emu_perm(uint32_t s0, uint32_t s1, uint32_t sel) {     // v_perm_b32, selector values 0..7 and 12 (zero byte)
     const uint64_t both = ((uint64_t)s0 << 32) | s1;
     uint32_t r = 0;
     for (int i = 0; i < 4; ++i) {
         const uint32_t k = (sel >> (8 * i)) & 0xff;
+        if (k == 12) continue;                                          // selector 0x0c: constant 0x00
         if (k > 7) { fprintf(stderr, "emu: v_perm selector %u is not modelled\n", k); abort(); }
         r |= (uint32_t)((both >> (8 * k)) & 0xff) << (8 * i);
     }

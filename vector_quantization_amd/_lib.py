@@ -49,6 +49,7 @@ SIGNATURES = {
     "vq_encode_l1_prepared_phases": (_i, [_vp, _vp, _sz, _i64, _i, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp]),
     "vq_workspace_counters_offset": (_sz, [_i, _i, _i64]),
     "vq_lbg_accum": (_i, [_vp, _vp, _sz, _i64, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "vq_lbg_pass_fused": (_i, [_i, _i]),
     "vq_lbg_state_bytes": (_sz, [_i]),
     "vq_lbg_stage_begin": (_i, [_vp, _sz, _i, _vp]),
     "vq_lbg_iterate": (_i, [_vp, _vp, _sz, _i64, _i, _vp, _i, _i64, _dbl, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _sz, _vp]),

@@ -51,6 +51,12 @@
 // that hipGetSymbolAddress returns for the current device (static_scratch below), never by this name.
 static __device__ __align__(256) unsigned char scratch[VQ_STATIC_SCRATCH_BYTES];
 
+#ifdef VQ_TIMELINE
+// Diagnostic builds only (never the shipped library): per wave of the last k_assign_fast launch, its start and
+// end time (100 MHz counter), hardware id register and the codebook rows it searched.
+static __device__ uint32_t g_timeline[8 << 18];
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -261,6 +267,36 @@ __device__ __forceinline__ uint32_t wave_reduce_u32(uint32_t v) {
     // scalar registers and table lookups indexed by it become scalar loads
     return __builtin_amdgcn_readfirstlane(op(op(r0, r1), op(r2, r3)));
 }
+
+// Scalar loads issued ahead of their use.  The compiler does not track when their data arrives (it would wait for it
+// at once): the registers may be read only after sload_wait, which every such load must be followed by.
+#ifndef VQ_HOST_EMULATION
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void sload_x16(u32x16 &r, const uint32_t *base, uint32_t byte_off) {
+    asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(r) : "s"(base), "s"(byte_off));
+}
+__device__ __forceinline__ void sload_x2(u32x2 &r, const uint32_t *base, uint32_t byte_off) {
+    asm volatile("s_load_dwordx2 %0, %1, %2" : "=&s"(r) : "s"(base), "s"(byte_off));
+}
+__device__ __forceinline__ void sload_wait(u32x16 &a, u32x2 &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)); }
+#else
+struct u32x16 {
+    uint32_t v[16];
+    uint32_t operator[](int i) const { return v[i]; }
+};
+struct u32x2 {
+    uint32_t v[2];
+    uint32_t operator[](int i) const { return v[i]; }
+};
+inline void sload_x16(u32x16 &r, const uint32_t *base, uint32_t byte_off) {
+    for (int i = 0; i < 16; ++i) r.v[i] = base[byte_off / 4 + i];
+}
+inline void sload_x2(u32x2 &r, const uint32_t *base, uint32_t byte_off) {
+    for (int i = 0; i < 2; ++i) r.v[i] = base[byte_off / 4 + i];
+}
+inline void sload_wait(u32x16 &, u32x2 &) {}
+#endif  // VQ_HOST_EMULATION
 
 // fp64 -> uint8 the way numpy converts inside np.array(..., dtype=np.uint8): truncate toward
 // zero and keep the low 8 bits; magnitudes beyond the int32 range (and NaN) give 0.
@@ -1749,6 +1785,9 @@ struct AssignArgs {
     const uint16_t *perm;       // N: position inside its window of the vector now at sorted position i
     const uint32_t *postab;     // sum threshold -> position in the sorted codebook
     const SortedHeader *shdr;   // what the sorted copy holds (verified before the origin map is trusted)
+    int64_t dist_sorted_end;    // PRUNE: the distances of the vectors at sorted positions below this go to min_dist at
+                                // their SORTED position (coalesced stores; the reader un-permutes), the others by origin
+    int heavy_first;            // PRUNE: 1 = tiles from the middle of the sort windows are dispatched first (few-round launches)
     Gate gate;
 };
 
@@ -1793,6 +1832,10 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
     //              ACC:    [(K + 1) rows of 2*DP2 byte sums | count | pad][per wave: 64 rows of EPL bytes, 64 labels]
     extern __shared__ __align__(16) uint32_t s_tab[];
     if (gate_closed(a.gate)) return;
+#ifdef VQ_TIMELINE
+    const uint32_t tl_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    uint32_t tl_rows = 0, tl_loaded = 0, tl_searched = 0, tl_resolved = 0;
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int BLOCK = blockDim.x;
@@ -1814,23 +1857,6 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
         __syncthreads();
     }
 
-    if (PRUNE) {
-        // (wave-uniform) the sorted copy must be the one made for these N vectors of d bytes; otherwise its
-        // origin map cannot be trusted: every label of this workgroup's tiles becomes -1 and nothing else
-        // is written
-        if (a.shdr->magic != SORTED_MAGIC || a.shdr->N != (unsigned long long)a.N || a.shdr->d != (uint32_t)a.d) {
-            for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-                for (int r = 0; r < R; ++r) {
-                    const int64_t n = tile * (int64_t)(BLOCK * R) + (int64_t)r * BLOCK + tid;
-                    if (n < a.N) a.labels[n] = -1;
-                }
-            }
-            return;
-        }
-    }
-    const uint32_t s = a.hdr->shift;
-    const uint32_t emax = a.hdr->emax;
-    const uint32_t window = emax >= 0x3fffffffu ? 0xffffffffu : 2u * emax;   // ambiguous iff S2 - S1 <= window
     const uint32_t kbits = (uint32_t)a.kbits;
     const uint32_t kmask = (1u << kbits) - 1u;
     // The shift count lives in a vector register: v_lshl_add_u32 can then take the per-codeword
@@ -1842,8 +1868,31 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
     // their labels and distances into the same 32 / 64 KB of output, so consecutive tiles are given to
     // workgroups of the same XCD (one L2 then sees all writes to a line before it is evicted).
     int64_t first_tile = blockIdx.x;
-    if (PRUNE && (gridDim.x & 7) == 0) first_tile = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    for (int64_t tile = first_tile; tile < a.ntiles; tile += gridDim.x) {
+    if (PRUNE && (gridDim.x & 7) == 0) {
+        const uint32_t tx = gridDim.x >> 3;
+        first_tile = (int64_t)(blockIdx.x & 7) * tx + (blockIdx.x >> 3);
+        // Launches of only a few rounds of workgroups (a.heavy_first): within an XCD's share, the tiles from the
+        // middle of every sort window -- the most codebook rows to search -- go first and those from its two ends
+        // last, so that the workgroups that start last are the short ones.
+        const uint32_t TPW = SORT_WIN / (blockDim.x * R);     // tiles per sort window
+        if (a.heavy_first && TPW >= 2 && tx % TPW == 0) {
+            const uint32_t nwin = tx / TPW, j = blockIdx.x >> 3;
+            uint32_t c = j / nwin;
+            const uint32_t w = j - c * nwin;
+            // a launch that is resident all at once (heavy_first = 2): the compute units of an XCD take its workgroups
+            // in turn, so the workgroups that share one are a fixed number of classes apart; running every other
+            // stretch of that many classes backwards puts long and short workgroups together
+            if (a.heavy_first == 2 && nwin <= 32 && 32 % nwin == 0) {
+                const uint32_t m = 32 / nwin;
+                if ((c / m) & 1) c = (c / m) * m + (m - 1 - c % m);
+            }
+            const uint32_t pos = (c & 1) ? TPW / 2 + (c >> 1) : TPW / 2 - 1 - (c >> 1);
+            first_tile = (int64_t)(blockIdx.x & 7) * tx + (int64_t)w * TPW + pos;
+        }
+    }
+    // One tile per workgroup (the host launches at least ntiles workgroups): nothing is carried from tile to tile, so
+    // no value has to stay live across the whole kernel.
+    if (const int64_t tile = first_tile; tile < a.ntiles) {
         const int64_t base = tile * (int64_t)(BLOCK * R);
         // ---- load R vectors per lane and convert to packed 16-bit fixed point ----
         uint32_t x[R][DP2];
@@ -1853,6 +1902,8 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
         auto vec_index = [&](int r) -> int64_t {
             return PRUNE ? base + (int64_t)(tid >> 6) * (WAVE * R) + r * WAVE + lane : base + (int64_t)r * BLOCK + tid;
         };
+        // The vectors are requested first and looked at last: the header reads below (three more memory round trips)
+        // run while they are on their way.  Word-wise rows wait in x[r][even] as they came.
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             int64_t n = vec_index(r);
@@ -1860,28 +1911,19 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
             const uint8_t *row = (PRUNE ? a.rows : a.blocks) + (size_t)n * d;
             origin[r] = PRUNE ? (uint32_t)a.perm[n] : 0u;
             // Out-of-row positions (d below the template's padded size) are loaded from a clamped
-            // index and then zeroed, so that no load sits behind a branch.
+            // index and zeroed later, so that no load sits behind a branch.
             if (DP2 == 8 && a.vec4 == 2) {
                 // 16-byte rows, 16-byte aligned: one load per vector
                 const uint4 v = *reinterpret_cast<const uint4 *>(row);
-                const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int wi = 0; wi < 4; ++wi) {
-                    const uint32_t w = w4[wi];
-                    x[r][2 * wi] = ((w & 0xffu) | ((w & 0xff00u) << 8)) << s;
-                    x[r][2 * wi + 1] = (((w >> 16) & 0xffu) | ((w >> 8) & 0xff0000u)) << s;
-                }
+                x[r][0] = v.x;
+                x[r][2] = v.y;
+                x[r][4] = v.z;
+                x[r][6] = v.w;
             } else if (a.vec4) {
                 const uint32_t *row4 = reinterpret_cast<const uint32_t *>(row);
                 const int nw = d >> 2;
 #pragma unroll
-                for (int p = 0; p < DP2; p += 2) {
-                    const int wi = p >> 1;
-                    uint32_t w = row4[wi < nw ? wi : 0];
-                    w = wi < nw ? w : 0u;
-                    x[r][p] = ((w & 0xffu) | ((w & 0xff00u) << 8)) << s;
-                    x[r][p + 1] = (((w >> 16) & 0xffu) | ((w >> 8) & 0xff0000u)) << s;
-                }
+                for (int p = 0; p < DP2; p += 2) x[r][p] = row4[(p >> 1) < nw ? (p >> 1) : 0];
             } else {
 #pragma unroll
                 for (int p = 0; p < DP2; ++p) {
@@ -1890,10 +1932,51 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
                     uint32_t b1 = row[e1 < d ? e1 : 0];
                     b0 = e0 < d ? b0 : 0u;
                     b1 = e1 < d ? b1 : 0u;
-                    x[r][p] = (b0 | (b1 << 16)) << s;
+                    x[r][p] = (b0 | (b1 << 16)) << 8;
                 }
             }
         }
+        if (PRUNE) {
+            // (wave-uniform) the sorted copy must be the one made for these N vectors of d bytes; otherwise its
+            // origin map cannot be trusted: every label of this workgroup's tile becomes -1 and nothing else
+            // is written
+            if (a.shdr->magic != SORTED_MAGIC || a.shdr->N != (unsigned long long)a.N || a.shdr->d != (uint32_t)a.d) {
+                for (int r = 0; r < R; ++r) {
+                    const int64_t n = base + (int64_t)r * BLOCK + tid;
+                    if (n < a.N) a.labels[n] = -1;
+                }
+                return;
+            }
+        }
+        const uint32_t s = a.hdr->shift;
+        const uint32_t emax = a.hdr->emax;
+        const uint32_t window = emax >= 0x3fffffffu ? 0xffffffffu : 2u * emax;   // ambiguous iff S2 - S1 <= window
+        uint32_t sh8_v = 8u - s;                               // (a vector register too: shifts by a scalar issue slower)
+        asm volatile("" : "+v"(sh8_v));
+        // bytes (0, 1) / (2, 3) of a word as a pair of 16-bit fixed-point values x << s: v_perm puts each byte into the
+        // upper byte of its half (x << 8), one right shift takes the pair down to x << s (s <= 8)
+        if (a.vec4) {
+            const int nw = d >> 2;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int p = 0; p < DP2; p += 2) {
+                    const uint32_t w = (p >> 1) < nw ? x[r][p] : 0u;
+                    x[r][p] = __builtin_amdgcn_perm(0u, w, 0x010c000cu) >> sh8_v;
+                    x[r][p + 1] = __builtin_amdgcn_perm(0u, w, 0x030c020cu) >> sh8_v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int p = 0; p < DP2; ++p) x[r][p] >>= sh8_v;
+            }
+        }
+#ifdef VQ_TIMELINE
+        __builtin_amdgcn_s_waitcnt(0x0f70);                    // vmcnt(0): the vectors have arrived
+        tl_loaded = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
         // ---- filter: two smallest keys per vector ----
         uint32_t rows_searched = 0;                            // codebook rows this wave evaluated (wave-uniform)
         int range_lo = 0, range_hi = 0;                        // RESOLVE: the rows [range_lo, range_hi) it searched
@@ -1930,23 +2013,80 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
             }
             finish(acc, b, k);
         };
+        // Two codewords at once (packed keys): with keys a and b, the new smallest is min3(a, b, m1) and the new
+        // second smallest min(med3(a, b, m1), m2) -- five instructions for the pair instead of six.
+        auto step2 = [&](const uint32_t *cw0, const uint32_t *cw1, uint32_t b0, uint32_t b1) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                uint32_t a0 = 0, a1 = 0;
+#pragma unroll
+                for (int p = 0; p < DP2; ++p) a0 = __builtin_amdgcn_sad_u16(x[r][p], cw0[p], a0);
+#pragma unroll
+                for (int p = 0; p < DP2; ++p) a1 = __builtin_amdgcn_sad_u16(x[r][p], cw1[p], a1);
+                const uint32_t k0 = (a0 << kbits_v) + b0, k1 = (a1 << kbits_v) + b1;
+                const uint32_t md = umed3(k0, k1, m1[r]);
+                m1[r] = min(min(k0, k1), m1[r]);
+                m2[r] = min(md, m2[r]);
+            }
+        };
         if constexpr (!LDS_CW) {
             // Codewords are fetched by scalar loads (wave-uniform addresses) in batches of U, so that
             // one scalar-memory wait is paid per U * R * (DP2 + 3) vector instructions.
             constexpr int U = DP2 <= 8 ? (PRUNE ? VQ_UP : VQ_U8) : (DP2 <= 16 ? 2 : 1);
             // rows [lo, hi) of the fixed-point codebook, hi - lo a multiple of U (rows K .. Kpad are
             // pad rows that never win)
+            // The rows of the next trip are requested before this trip's arithmetic starts, so that the wave does
+            // not sit out a scalar-memory round trip per batch (the last trip re-reads its own rows).
             auto run = [&](int lo, int hi) {
-                for (int k = lo; k < hi; k += U) {
-                    uint32_t cw[U][DP2], b[U];
+                if (lo >= hi) return;                          // (wave-uniform)
+                if constexpr (DP2 == 8 && U == 2 && KEYMODE == KEY_PACKED) {
+                    // two 32-byte rows are one 64-byte scalar load, their biases one 8-byte load (lo is even)
+                    u32x16 cur;
+                    u32x2 cb2;
+                    sload_x16(cur, c16, (uint32_t)lo * 32u);
+                    sload_x2(cb2, bias, (uint32_t)lo * 4u);
+                    sload_wait(cur, cb2);
+                    for (int k = lo; k < hi; k += 2) {
+                        u32x16 nxt;
+                        u32x2 nb2;
+                        const uint32_t kn = (uint32_t)(k + 2 < hi ? k + 2 : k);
+                        sload_x16(nxt, c16, kn * 32u);
+                        sload_x2(nb2, bias, kn * 4u);
+                        __builtin_amdgcn_sched_barrier(0);     // the requests go out before the arithmetic, not after it
+                        const uint32_t cw0[8] = {cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6], cur[7]};
+                        const uint32_t cw1[8] = {cur[8], cur[9], cur[10], cur[11], cur[12], cur[13], cur[14], cur[15]};
+                        step2(cw0, cw1, cb2[0], cb2[1]);
+                        sload_wait(nxt, nb2);
+                        cur = nxt;
+                        cb2 = nb2;
+                    }
+                    return;
+                }
+                uint32_t cw[U][DP2], b[U];
+                auto fetch = [&](uint32_t (*w)[DP2], uint32_t *bb, int k) {
 #pragma unroll
                     for (int j = 0; j < U; ++j) {
 #pragma unroll
-                        for (int p = 0; p < DP2; ++p) cw[j][p] = c16[(size_t)(k + j) * DP2 + p];
-                        b[j] = bias[k + j];
+                        for (int p = 0; p < DP2; ++p) w[j][p] = c16[(size_t)(k + j) * DP2 + p];
+                        bb[j] = bias[k + j];
+                    }
+                };
+                fetch(cw, b, lo);
+                for (int k = lo; k < hi; k += U) {
+                    uint32_t nw[U][DP2], nb[U];
+                    fetch(nw, nb, k + U < hi ? k + U : k);
+                    if constexpr (U == 2 && KEYMODE == KEY_PACKED) {
+                        step2(cw[0], cw[1], b[0], b[1]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < U; ++j) step(cw[j], b[j], k + j);
                     }
 #pragma unroll
-                    for (int j = 0; j < U; ++j) step(cw[j], b[j], k + j);
+                    for (int j = 0; j < U; ++j) {
+#pragma unroll
+                        for (int p = 0; p < DP2; ++p) cw[j][p] = nw[j][p];
+                        b[j] = nb[j];
+                    }
                 }
             };
             const int kpad = (K + 7) & ~7;
@@ -1966,7 +2106,8 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
                 }
                 sxlo = wave_reduce_u32<false>(sxlo);
                 sxhi = wave_reduce_u32<true>(sxhi);
-                const uint32_t tshift = a.hdr->tshift, nt = a.hdr->nt;
+                // (marked wave-uniform: the table look-ups below then are scalar loads)
+                const uint32_t tshift = __builtin_amdgcn_readfirstlane(a.hdr->tshift), nt = __builtin_amdgcn_readfirstlane(a.hdr->nt);
                 constexpr int G = VQ_GP;                       // codewords added per side and round
                 constexpr int G0 = VQ_G0;                      // codewords of the first round, around the wave's own sum
                 int pa = (int)(a.postab[((sxlo >> 1) + (sxhi >> 1)) >> tshift] & ~7u) - G0 / 2;
@@ -2006,7 +2147,7 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
             constexpr int TILE_K = tile_k_for(DP2);
             constexpr int TILE_W = TILE_K * DP2;               // words of fixed-point rows per tile
             constexpr int NV = TILE_W / 4;                     // 16-byte pieces per tile
-            constexpr int MAXL = (NV + 255) / 256;             // pieces per thread (workgroups have >= 256 threads)
+            constexpr int MAXL = (NV + 127) / 128;             // pieces per thread (workgroups have >= 128 threads)
             uint32_t *s_cw = s_tab;
             uint32_t *s_b = s_cw + 2 * TILE_W;
             const int ntk = (K + TILE_K - 1) / TILE_K;
@@ -2170,6 +2311,9 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
                 rows_searched = (uint32_t)((tb - ta) * TILE_K);
             }
         }
+#ifdef VQ_TIMELINE
+        tl_searched = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
         // ---- near-ties settled in the kernel (RESOLVE) ----
         // the outcome replaces the vector's keys: the winner, and no runner-up
         if constexpr (RESOLVE) {
@@ -2236,6 +2380,10 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
                 }
             }
         }
+#ifdef VQ_TIMELINE
+        tl_rows += rows_searched;
+        tl_resolved = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
         // statistics: (vector, codeword) pairs this wave evaluated, summed into the 64-bit word at byte 8 of
         // the wave's sub-queue slot
         if (lane == 0)
@@ -2312,7 +2460,7 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging area is rewritten by the next group
             }
             if (!settled) continue;
-            a.labels[n] = idx;
+            if (a.labels) a.labels[n] = idx;                   // (null: the fused LBG pass of a training run)
             if (want_dist) {
                 const double *crow = a.cb + (size_t)idx * d;
                 double acc = 0.0;
@@ -2327,10 +2475,24 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
                         }
                     }
                 }
-                a.min_dist[n] = acc;
+                a.min_dist[PRUNE && ns < a.dist_sorted_end ? ns : n] = acc;
             }
         }
     }
+#ifdef VQ_TIMELINE
+    {
+        const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (tid >> 6);
+        if (lane == 0 && w < (1u << 18)) {
+            g_timeline[8 * w] = tl_t0;
+            g_timeline[8 * w + 1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+            g_timeline[8 * w + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | (__builtin_amdgcn_s_getreg((3 << 11) | 20) << 28);   // HW_ID | XCC_ID << 28
+            g_timeline[8 * w + 3] = tl_rows;
+            g_timeline[8 * w + 4] = tl_loaded;
+            g_timeline[8 * w + 5] = tl_searched;
+            g_timeline[8 * w + 6] = tl_resolved;
+        }
+    }
+#endif
     if (ACC) {
         __syncthreads();
         unsigned long long *rep = a.acc_rep + (size_t)(blockIdx.x % NREP) * (K * (d + 1));
@@ -2395,7 +2557,7 @@ __global__ __launch_bounds__(1024) void k_fixup(const uint8_t *__restrict__ bloc
         for (int i = threadIdx.x; i < n; i += blockDim.x) s_cbT[i] = cbT[i];
         __syncthreads();
     }
-    const uint32_t count = qcount[16 * sub];
+    const uint32_t count = min(qcount[16 * sub], qcap);       // a counter nobody reset must not lead past the sub-queue
     queue += (size_t)sub * qcap;
     for (uint32_t i0 = rank; i0 < count; i0 += 4 * nwaves) {
         int64_t n[4], m[4];                                    // row to read; vector index to write
@@ -2487,7 +2649,7 @@ __global__ __launch_bounds__(1024) void k_fixup_pruned(const uint8_t *__restrict
     }
     const uint32_t shift = hdr->shift, emax = hdr->emax, tshift = hdr->tshift, nt = hdr->nt;
     const double scale = (double)(1u << shift);
-    const uint32_t count = qcount[16 * sub];
+    const uint32_t count = min(qcount[16 * sub], qcap);       // a counter nobody reset must not lead past the sub-queue
     queue += (size_t)sub * qcap;
     // A wave serves the entries rank, rank + nwaves, ... of its sub-queue.  It reads them 64 at a time (one entry
     // per lane, one load), so that an item costs one memory round trip -- the vector's bytes and its origin, which
@@ -2663,7 +2825,7 @@ __global__ __launch_bounds__(256) void k_fixup_shortlist(const uint8_t *__restri
     if (gate_closed(gate)) return;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
     const uint32_t sub = blockIdx.x & (NQ - 1), rank = blockIdx.x / NQ, nwg = gridDim.x / NQ;
-    const uint32_t count = qcount[16 * sub];
+    const uint32_t count = min(qcount[16 * sub], qcap);       // a counter nobody reset must not lead past the sub-queue
     if (rank >= count) return;                                  // (workgroup-uniform)
     const uint32_t shift = hdr->shift, emax = hdr->emax, tshift = hdr->tshift, nt = hdr->nt;
     const uint32_t window = emax >= 0x3fffffffu ? 0xffffffffu : 2u * emax;
@@ -2990,10 +3152,42 @@ __global__ __launch_bounds__(1024) void k_npsum_final(const double *__restrict__
 // tables into sums / counts -- leaving the replicas zeroed for the next iteration -- and sums its 8192-element
 // chunks of the winning distances.  k_lbg_finish (one workgroup): the chunk sums in numpy's order, the centroid
 // update in place and the stop rule.
-__global__ __launch_bounds__(512) void k_lbg_fold(const double *__restrict__ min_dist, int64_t nfull,
+// perm non-null: the distances of the full chunks lie in the order of the window-sorted vectors (a chunk is a sort
+// window); the workgroup puts a chunk back into the caller's order in LDS (64 KB) and sums it from there.
+static_assert(SORT_WIN == NP_CHUNK, "a sort window is one summation chunk");
+__device__ __forceinline__ void npsum_chunk_sorted(const double *__restrict__ v, const uint16_t *__restrict__ perm, int64_t c,
+                                                   double *__restrict__ chunk_sums, double *s_leaf, double *s_d) {
+    const int tid = threadIdx.x;
+    const double *src = v + c * NP_CHUNK;
+    const uint16_t *pp = perm + c * NP_CHUNK;
+#pragma unroll 4
+    for (int i = tid; i < (int)NP_CHUNK; i += 512) s_d[pp[i] & (NP_CHUNK - 1)] = src[i];
+    __syncthreads();
+    const int j = tid & 7, leaf = tid >> 3;                    // 64 leaves x 8 lanes, as in npsum_chunk
+    const double *a = s_d + leaf * 128 + j;
+    double r = a[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) r += a[8 * i];
+    r += __shfl_xor(r, 1, WAVE);
+    r += __shfl_xor(r, 2, WAVE);
+    r += __shfl_xor(r, 4, WAVE);
+    if (j == 0) s_leaf[leaf] = r;
+    __syncthreads();
+    if (tid < WAVE) {
+        double u = s_leaf[tid];
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) u += __shfl_xor(u, off, WAVE);
+        if (tid == 0) chunk_sums[c] = u;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(512) void k_lbg_fold(const double *__restrict__ min_dist, const uint16_t *__restrict__ perm,
+                                                  int64_t nfull,
                                                   double *__restrict__ chunk_sums, unsigned long long *__restrict__ rep,
                                                   int K, int d, unsigned long long *__restrict__ sums,
                                                   unsigned long long *__restrict__ counts, Gate g) {
+    extern __shared__ __align__(16) double s_dist[];            // perm non-null: one chunk of distances
     __shared__ double s_leaf[64];
     if (gate_closed(g)) return;
     const int tid = threadIdx.x;
@@ -3009,7 +3203,11 @@ __global__ __launch_bounds__(512) void k_lbg_fold(const double *__restrict__ min
         if (e < d) sums[(size_t)kk * d + e] = t;
         else counts[kk] = t;
     }
-    for (int64_t c = blockIdx.x; c < nfull; c += gridDim.x) npsum_chunk(min_dist, c, chunk_sums, s_leaf);
+    if (perm) {
+        for (int64_t c = blockIdx.x; c < nfull; c += gridDim.x) npsum_chunk_sorted(min_dist, perm, c, chunk_sums, s_leaf, s_dist);
+    } else {
+        for (int64_t c = blockIdx.x; c < nfull; c += gridDim.x) npsum_chunk(min_dist, c, chunk_sums, s_leaf);
+    }
 }
 
 __global__ __launch_bounds__(1024) void k_lbg_finish(const double *__restrict__ min_dist, int64_t N, int64_t nfull,
@@ -3676,7 +3874,7 @@ bool fused_acc_supported(const void *sorted, int K, int d) {
 // sums / counts non-null (only with fused_acc_supported): cluster sums are accumulated too.
 int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d, const double *cb, int K,
              int32_t *labels, double *min_dist, unsigned long long *sums, unsigned long long *counts, void *ws,
-             hipStream_t st, int phases = 3) {
+             hipStream_t st, int phases = 3, bool dist_sorted = false) {
     const int dp2 = dp2_bucket(d);
     if (sorted != nullptr && prune_supported(K, d)) {          // before any work is enqueued
         int src = sorted_check(sorted, sorted_bytes, N, d);
@@ -3704,7 +3902,12 @@ int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int
     const bool prune = sorted != nullptr && prune_supported(K, d);
     const bool lds_cw = prune ? !prune_by_scalar_loads(K, dp2) : use_lds_codewords(K, dp2);
     const int R = lds_cw ? r_lds_for(dp2) : (prune ? r_prune_for(dp2) : r_for(dp2));
-    const int block = 256;
+    // The LDS-tiled pruned search with no more workgroups than the chip holds at once takes workgroups of two waves:
+    // four small workgroups per compute unit even out better than two large ones.
+    int block = 256;
+#ifdef VQ_SMALL_WG
+    if (prune && lds_cw && (N + 256 * R - 1) / (256 * R) <= (int64_t)di.cus * VQ_SMALL_WG) block = 128;
+#endif
     if (sums && !fused_acc_supported(sorted, K, d)) return fail(VQ_E_HIP, "internal: fused accumulation is not available here");
     // LDS-staged codewords: two tiles of rows and biases, plus the words of the workgroup reductions
     const size_t lds = lds_cw ? (size_t)2 * tile_k_for(dp2) * (dp2 + 1) * 4 + 128 : (sums ? fused_acc_lds(K, d) : 0);
@@ -3712,7 +3915,8 @@ int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int
     const int64_t ntiles = (N + tile - 1) / tile;
     // One tile per workgroup: the dispatcher balances the chip and the last, partly filled round of
     // workgroups runs at full clock (measured faster than any persistent grid).
-    int grid = (int)(ntiles < ((int64_t)1 << 30) ? ntiles : ((int64_t)1 << 30));
+    if (ntiles > ((int64_t)1 << 30)) return fail(VQ_E_UNSUPPORTED, "N=%lld needs more than 2^30 workgroups", (long long)N);
+    int grid = (int)ntiles;
     if (prune && grid >= 8) grid = (grid + 7) & ~7;               // a multiple of the XCD count (see the kernel's tile order)
     if (grid < 1) grid = 1;
 
@@ -3729,6 +3933,8 @@ int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int
     a.vec4 = ((d & 3) == 0) && ((reinterpret_cast<uintptr_t>(blocks) & 3) == 0);
     if (d == 16 && (reinterpret_cast<uintptr_t>(blocks) & 15) == 0) a.vec4 = 2;     // whole 16-byte rows
     a.rows = nullptr; a.perm = nullptr; a.shdr = nullptr;
+    a.dist_sorted_end = (prune && dist_sorted) ? N / NP_CHUNK * NP_CHUNK : 0;
+    a.heavy_first = (prune && grid <= 16 * di.cus) ? (grid <= 4 * di.cus ? 2 : 1) : 0;
     a.gate = g_gate;
     a.postab = reinterpret_cast<const uint32_t *>(w + L.postab);
     if (prune) {
@@ -3744,16 +3950,18 @@ int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int
 
     if (do_filter)
     switch (dp2) {
+#ifndef VQ_FEW_SHAPES                                       // (experimental builds compile three row lengths only)
         case 2:  rc = launch_assign_fast_k<2>(a, c16, bias, packed, lds_cw, prune, block, grid, lds, st); break;
         case 4:  rc = launch_assign_fast_k<4>(a, c16, bias, packed, lds_cw, prune, block, grid, lds, st); break;
         case 6:  rc = launch_assign_fast_k<6>(a, c16, bias, packed, lds_cw, prune, block, grid, lds, st); break;
-        case 8:  rc = launch_assign_fast_k<8>(a, c16, bias, packed, lds_cw, prune, block, grid, lds, st); break;
         case 12: rc = launch_assign_fast_k<12>(a, c16, bias, packed, lds_cw, prune, block, grid, lds, st); break;
         case 16: rc = launch_assign_fast_k<16>(a, c16, bias, packed, lds_cw, prune, block, grid, lds, st); break;
-        case 24: rc = launch_assign_fast_k<24>(a, c16, bias, packed, lds_cw, prune, block, grid, lds, st); break;
         case 32: rc = launch_assign_fast_k<32>(a, c16, bias, packed, lds_cw, prune, block, grid, lds, st); break;
         case 48: rc = launch_assign_fast_k<48>(a, c16, bias, packed, lds_cw, prune, block, grid, lds, st); break;
         case 64: rc = launch_assign_fast_k<64>(a, c16, bias, packed, lds_cw, prune, block, grid, lds, st); break;
+#endif
+        case 8:  rc = launch_assign_fast_k<8>(a, c16, bias, packed, lds_cw, prune, block, grid, lds, st); break;
+        case 24: rc = launch_assign_fast_k<24>(a, c16, bias, packed, lds_cw, prune, block, grid, lds, st); break;
         case 96: rc = launch_assign_fast_k<96>(a, c16, bias, packed, lds_cw, prune, block, grid, lds, st); break;
         default: return fail(VQ_E_UNSUPPORTED, "no fast kernel for d=%d", d);
     }
@@ -3969,6 +4177,16 @@ int run_sort(const SRC &src, bool row_words_ok, int64_t N, int d, void *sorted, 
 extern "C" {
 
 int vq_abi_version(void) { return ABI_VERSION; }
+
+#ifdef VQ_TIMELINE
+// Diagnostic builds only: copies the wave timeline of the last k_assign_fast launch to the host (synchronises).
+int vq_debug_timeline(uint32_t *h_out, size_t words) {
+    if (words > (size_t)(8 << 18)) words = (size_t)(8 << 18);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_timeline), words * 4, 0, hipMemcpyDeviceToHost));
+    return VQ_OK;
+}
+#endif
 
 const char *vq_last_error(void) { return g_err; }
 
@@ -4260,6 +4478,11 @@ int vq_lbg_accum(const uint8_t *blocks, const void *sorted, size_t sorted_bytes,
     return run_numpy_sum(min_dist, N, cs, dist_sum, st);
 }
 
+int vq_lbg_pass_fused(int K, int d) {
+    static const char dummy = 0;                               // (any non-null `sorted`: only the shape decides)
+    return (K > 0 && d > 0 && fast_supported(d) && fused_acc_supported(&dummy, K, d)) ? 1 : 0;
+}
+
 size_t vq_lbg_state_bytes(int max_iterations) {
     if (max_iterations < 1) return 0;
     return align_up(offsetof(LbgState, rec) + (size_t)max_iterations * sizeof(LbgRecord), 256);
@@ -4301,7 +4524,7 @@ int vq_lbg_iterate(const uint8_t *blocks, const void *sorted, size_t sorted_byte
     // (same workspace, same state, iteration numbers counting up, no other call on the workspace in between)
     // zeroes them.
     const bool fused = N > 0 && mode == VQ_MODE_FAST && fast_supported(d) && fused_acc_supported(sorted, K, d) &&
-                       labels != nullptr && min_dist != nullptr;
+                       min_dist != nullptr;
     if (fused) {
         rc = check_common(blocks, N, d, cb, K, true);
         if (rc) return rc;
@@ -4318,8 +4541,10 @@ int vq_lbg_iterate(const uint8_t *blocks, const void *sorted, size_t sorted_byte
         g_ws_zeroed = true;
         rc = run_prepare(cb, K, d, ws, st);
         if (rc) return rc;
+        // the winning distances of whole chunks are stored in the order of the sorted vectors (full-width stores) and
+        // put back into the caller's order by the fold kernel, in LDS; labels are written only when asked for
         rc = run_fast(blocks, sorted, sorted_bytes, N, d, cb, K, labels, min_dist, reinterpret_cast<unsigned long long *>(sums),
-                      reinterpret_cast<unsigned long long *>(counts), ws, st, 1);
+                      reinterpret_cast<unsigned long long *>(counts), ws, st, 1, true);
         if (rc) return rc;
         const int64_t nfull = N / NP_CHUNK;
         const int tabn = K * (d + 1);
@@ -4328,7 +4553,11 @@ int vq_lbg_iterate(const uint8_t *blocks, const void *sorted, size_t sorted_byte
         double *chunk_sums = reinterpret_cast<double *>(w + LN.chunks);
         unsigned long long *s64 = reinterpret_cast<unsigned long long *>(sums);
         unsigned long long *c64 = reinterpret_cast<unsigned long long *>(counts);
-        hipLaunchKernelGGL(k_lbg_fold, dim3((unsigned)grid), dim3(512), 0, st, min_dist, nfull, chunk_sums,
+        const uint16_t *perm = reinterpret_cast<const uint16_t *>(static_cast<const char *>(sorted) + sorted_layout(d, N).perm);
+        const size_t fold_lds = (size_t)NP_CHUNK * sizeof(double);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lbg_fold), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)fold_lds));
+        hipLaunchKernelGGL(k_lbg_fold, dim3((unsigned)grid), dim3(512), fold_lds, st, min_dist, perm, nfull, chunk_sums,
                            reinterpret_cast<unsigned long long *>(w + L0.acc_rep), K, d, s64, c64, g_gate);
         LAUNCH_CHECK("k_lbg_fold");
         hipLaunchKernelGGL(k_lbg_finish, dim3(1), dim3(1024), 0, st, min_dist, N, nfull, chunk_sums, s64, c64, cb, K, d,

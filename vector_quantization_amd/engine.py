@@ -288,6 +288,9 @@ class HipEngine:
             self._scratch_n = N
         ws = self._workspace(K, d, N)
         use_mode = self.mode if mode is None else mode
+        # the fused pass writes labels only when given a buffer for them: training does not need any
+        lab = None if (sorted is not None and use_mode == VQ_MODE_FAST and lib.vq_lbg_pass_fused(int(K), int(d))) \
+            else self._labels_scratch
         with torch.cuda.device(self.device):
             check(lib.vq_lbg_stage_begin(_ptr(state), nstate, int(limit), self._stream()), "vq_lbg_stage_begin")
 
@@ -295,7 +298,7 @@ class HipEngine:
             with torch.cuda.device(self.device):
                 check(lib.vq_lbg_iterate(_ptr(blocks), _ptr(sorted), _nbytes(sorted), N, d, _ptr(cb), K, int(n_total),
                                          float(threshold), j, _ptr(acc[: K * d]), _ptr(acc[K * d:]),
-                                         _ptr(self._labels_scratch), _ptr(self._dist_scratch), use_mode, _ptr(state),
+                                         _ptr(lab), _ptr(self._dist_scratch), use_mode, _ptr(state),
                                          nstate, _ptr(ws), ws.numel(), self._stream()), "vq_lbg_iterate")
             return self._mark()
 
