@@ -1787,6 +1787,7 @@ struct AssignArgs {
     const SortedHeader *shdr;   // what the sorted copy holds (verified before the origin map is trusted)
     int64_t dist_sorted_end;    // PRUNE: the distances of the vectors at sorted positions below this go to min_dist at
                                 // their SORTED position (coalesced stores; the reader un-permutes), the others by origin
+    int cb_lds;                 // ACC: 1 = the fp64 codebook is staged in LDS (rows of d + 1 doubles) for the winners' distances
     int heavy_first;            // PRUNE: 1 = tiles from the middle of the sort windows are dispatched first (few-round launches)
     Gate gate;
 };
@@ -1824,7 +1825,7 @@ constexpr int tile_k_for(int dp2) { return dp2 <= 8 ? 128 : (dp2 <= 16 ? 64 : (d
 // stages its 64 rows and labels in LDS and re-reads them transposed -- 64 / EPL vectors x EPL
 // elements per instruction -- so that one atomic instruction spreads over 16+ distinct addresses.
 template <int DP2, int R, int KEYMODE, bool LDS_CW, bool PRUNE, bool ACC = false>
-__global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const AssignArgs a, const uint32_t *__restrict__ c16,
+__global__ __launch_bounds__(ACC ? 1024 : 512) VQ_ASSIGN_ATTR void k_assign_fast(const AssignArgs a, const uint32_t *__restrict__ c16,
                                                      const uint32_t *__restrict__ bias,
                                                      const double *__restrict__ cbrows) {
     static_assert(!ACC || (PRUNE && DP2 <= 16), "the fused accumulation belongs to the pruned variant");
@@ -1852,8 +1853,18 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
     const int tabn = K * TROW;
     uint8_t *st_rows = reinterpret_cast<uint8_t *>(s_tab + ((tabn + TROW + 3) & ~3)) + (tid >> 6) * (WAVE * EPL + WAVE * 4);
     int32_t *st_lbl = reinterpret_cast<int32_t *>(st_rows + WAVE * EPL);
+    // ACC with a.cb_lds: the fp64 codebook behind the staging areas, rows padded to d + 1 doubles (lanes read the same
+    // element of different rows: the odd stride spreads them over the banks)
+    double *s_cbl = reinterpret_cast<double *>(reinterpret_cast<uint8_t *>(s_tab + ((tabn + TROW + 3) & ~3)) +
+                                               (BLOCK >> 6) * (WAVE * EPL + WAVE * 4));
     if (ACC) {
         for (int i = tid; i < tabn; i += BLOCK) s_tab[i] = 0u;
+        if (a.cb_lds) {
+            for (int i = tid; i < K * d; i += BLOCK) {
+                const int kk = i / d;
+                s_cbl[kk * (d + 1) + (i - kk * d)] = a.cb[i];
+            }
+        }
         __syncthreads();
     }
 
@@ -2462,19 +2473,24 @@ __global__ __launch_bounds__(512) VQ_ASSIGN_ATTR void k_assign_fast(const Assign
             if (!settled) continue;
             if (a.labels) a.labels[n] = idx;                   // (null: the fused LBG pass of a training run)
             if (want_dist) {
-                const double *crow = a.cb + (size_t)idx * d;
                 double acc = 0.0;
+                auto measure = [&](const double *crow) {
 #pragma unroll
-                for (int p = 0; p < DP2; ++p) {
+                    for (int p = 0; p < DP2; ++p) {
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        int e = 2 * p + h;
-                        if (e < d) {
-                            double xv = (double)((x[r][p] >> (s + 16 * h)) & 0xffu);
-                            acc += fabs(xv - crow[e]);
+                        for (int h = 0; h < 2; ++h) {
+                            int e = 2 * p + h;
+                            if (e < d) {
+                                double xv = (double)((x[r][p] >> (s + 16 * h)) & 0xffu);
+                                acc += fabs(xv - crow[e]);
+                            }
                         }
                     }
-                }
+                };
+                // every lane reads another codeword: from global memory that is 64 cache lines per load instruction,
+                // from the LDS copy a conflict-free read
+                if (ACC && a.cb_lds) measure(s_cbl + idx * (d + 1));
+                else measure(a.cb + (size_t)idx * d);
                 a.min_dist[PRUNE && ns < a.dist_sorted_end ? ns : n] = acc;
             }
         }
@@ -3860,10 +3876,15 @@ bool prune_supported(int K, int d) {
 // FAST mode on a prepared workspace: the filter kernel, then the fp64 fix-up of the vectors it
 // queued.  Writes labels and, when min_dist is non-null, the winning fp64 distances.
 // LDS bytes of the fused accumulation (table + per-wave staging) for a 256-thread workgroup.
-size_t fused_acc_lds(int K, int d) {
+size_t fused_acc_lds(int K, int d, int waves = 4) {
     const int dp2 = dp2_bucket(d);
-    return ((size_t)(K + 1) * (2 * dp2 + 2) + 3) / 4 * 16 + (size_t)4 * (WAVE * 2 * dp2 + WAVE * 4);
+    return ((size_t)(K + 1) * (2 * dp2 + 2) + 3) / 4 * 16 + (size_t)waves * (WAVE * 2 * dp2 + WAVE * 4);
 }
+// The fused pass with the fp64 codebook in LDS as well: workgroups of VQ_ACC_WAVES waves, two of them per compute unit.
+#ifndef VQ_ACC_WAVES
+#define VQ_ACC_WAVES 12
+#endif
+size_t fused_acc_cb_lds(int K, int d) { return fused_acc_lds(K, d, VQ_ACC_WAVES) + (size_t)K * (d + 1) * 8; }
 
 // Whether run_fast can accumulate sums / counts itself (pruned kernel, table within a quarter of the LDS).
 bool fused_acc_supported(const void *sorted, int K, int d) {
@@ -3905,12 +3926,15 @@ int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int
     // The LDS-tiled pruned search with no more workgroups than the chip holds at once takes workgroups of two waves:
     // four small workgroups per compute unit even out better than two large ones.
     int block = 256;
+    const bool acc_cb_lds = sums != nullptr && min_dist != nullptr && fused_acc_cb_lds(K, d) <= 80 * 1024;
+    if (acc_cb_lds) block = 64 * VQ_ACC_WAVES;
 #ifdef VQ_SMALL_WG
     if (prune && lds_cw && (N + 256 * R - 1) / (256 * R) <= (int64_t)di.cus * VQ_SMALL_WG) block = 128;
 #endif
     if (sums && !fused_acc_supported(sorted, K, d)) return fail(VQ_E_HIP, "internal: fused accumulation is not available here");
     // LDS-staged codewords: two tiles of rows and biases, plus the words of the workgroup reductions
-    const size_t lds = lds_cw ? (size_t)2 * tile_k_for(dp2) * (dp2 + 1) * 4 + 128 : (sums ? fused_acc_lds(K, d) : 0);
+    const size_t lds = lds_cw ? (size_t)2 * tile_k_for(dp2) * (dp2 + 1) * 4 + 128
+                              : (sums ? (acc_cb_lds ? fused_acc_cb_lds(K, d) : fused_acc_lds(K, d)) : 0);
     const int64_t tile = (int64_t)block * R;
     const int64_t ntiles = (N + tile - 1) / tile;
     // One tile per workgroup: the dispatcher balances the chip and the last, partly filled round of
@@ -3934,6 +3958,7 @@ int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int
     if (d == 16 && (reinterpret_cast<uintptr_t>(blocks) & 15) == 0) a.vec4 = 2;     // whole 16-byte rows
     a.rows = nullptr; a.perm = nullptr; a.shdr = nullptr;
     a.dist_sorted_end = (prune && dist_sorted) ? N / NP_CHUNK * NP_CHUNK : 0;
+    a.cb_lds = acc_cb_lds ? 1 : 0;
     a.heavy_first = (prune && grid <= 16 * di.cus) ? (grid <= 4 * di.cus ? 2 : 1) : 0;
     a.gate = g_gate;
     a.postab = reinterpret_cast<const uint32_t *>(w + L.postab);
@@ -3945,7 +3970,9 @@ int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int
         a.shdr = reinterpret_cast<const SortedHeader *>(sp + SL.hdr);
         a.vec4 = ((d & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.rows) & 3) == 0);
         if (d == 16 && (reinterpret_cast<uintptr_t>(a.rows) & 15) == 0) a.vec4 = 2;
-        if (SORT_WIN % tile != 0) return fail(VQ_E_HIP, "internal: sort window %d is not a multiple of the tile %lld", SORT_WIN, (long long)tile);
+        // a wave's vectors must come from one sort window; the LDS-tiled search needs that of a whole workgroup
+        if (SORT_WIN % (lds_cw ? tile : (int64_t)WAVE * R) != 0)
+            return fail(VQ_E_HIP, "internal: sort window %d is not a multiple of the tile %lld", SORT_WIN, (long long)tile);
     }
 
     if (do_filter)
