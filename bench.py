@@ -51,6 +51,67 @@ def _cpu_shard(args):
     return o.scipy_encode_chunked(blocks, cb, chunk=65536)
 
 
+def _cpu_lbg_shard(args):
+    """Per-cluster integer sums / counts and the distance partial of one shard (the reference arithmetic of
+    VQ_Full.py:77-90 up to the division)."""
+    from oracle import vq_oracle as o
+    blocks, cb = args
+    labels, mind = o.scipy_encode_chunked(blocks, cb, chunk=65536, want_dist=True)
+    K, d = cb.shape
+    sums = np.zeros((K, d), dtype=np.int64)
+    np.add.at(sums, labels, blocks.astype(np.int64))
+    counts = np.bincount(labels, minlength=K).astype(np.int64)
+    return sums, counts, float(mind.sum())
+
+
+def cpu_lbg_main(path):
+    """One LBG iteration of the reference arithmetic (chunked cdist + argmin + per-cluster mean, VQ_Full.py:77-90)
+    on the sample: one core, then sharded over P worker processes with the integer sums reduced on the parent."""
+    import multiprocessing as mp
+    from oracle import vq_oracle as o
+    z = np.load(path)
+    blocks, cb = z["blocks"], z["cb"]
+    n = blocks.shape[0]
+    t0 = time.perf_counter()
+    new_cb, D = o.scipy_lbg_iter_chunked(blocks, cb, chunk=65536)
+    t1 = time.perf_counter() - t0
+    procs = max(1, min(16, os.cpu_count() or 1))
+    shards = [(blocks[i * n // procs:(i + 1) * n // procs], cb) for i in range(procs)]
+    with mp.get_context("fork").Pool(procs) as pool:
+        pool.map(_cpu_lbg_shard, [(blocks[:1024], cb)] * procs)
+        t0 = time.perf_counter()
+        parts = pool.map(_cpu_lbg_shard, shards)
+        sums = sum(p[0] for p in parts)
+        counts = sum(p[1] for p in parts)
+        par_cb = np.where(counts[:, None] > 0, sums / np.maximum(counts, 1)[:, None], cb)
+        tp = time.perf_counter() - t0
+    np.save(path + ".newcb.npy", new_cb)
+    print(json.dumps(dict(
+        value=n / t1, unit="block-vectors/s per LBG iteration", iterations_per_s_at_sample=1.0 / t1, cores=1, kind="port",
+        seconds=t1, distortion=float(D),
+        sample=f"one iteration over {n} of the workload's block vectors, K={cb.shape[0]}, d={cb.shape[1]}: scipy cdist + "
+               f"argmin in 65536-vector chunks, per-cluster np.mean, np.mean of the winning distances; one core",
+        all_cores=dict(value=n / tp, unit="block-vectors/s per LBG iteration", cores=procs, seconds=tp,
+                       codebook_equal_one_core=bool(np.array_equal(par_cb, new_cb)),
+                       sample=f"the same vectors sharded over {procs} worker processes, integer sums / counts reduced "
+                              f"on the parent, one divide"))))
+
+
+def cpu_encode_sample_main(path):
+    """Encode-only figure on a sample of another shape (K = 1024 at d = 16, K = 4096 at d = 192): one core."""
+    from oracle import vq_oracle as o
+    z = np.load(path)
+    blocks, cb = z["blocks"], z["cb"]
+    n = blocks.shape[0]
+    t0 = time.perf_counter()
+    labels = o.scipy_encode_chunked(blocks, cb, chunk=8192 if cb.shape[0] > 1024 else 65536)
+    t1 = time.perf_counter() - t0
+    np.save(path + ".labels.npy", labels)
+    print(json.dumps(dict(value=n / t1, unit="block-vectors/s (encode only)", cores=1, kind="port", seconds=t1,
+                          sample=f"{n} block vectors, K={cb.shape[0]}, d={cb.shape[1]}: scipy cdist + argmin, one core; "
+                                 f"throughput is per vector, so larger images scale linearly")))
+
+
 def cpu_baseline_main(path):
     """Reference arithmetic on the host: scipy cdist('cityblock') + argmin in 65 536-vector chunks
     (VQ_Full.py:124-125) and the decode loop restated in C (VQ_Full.py:157-169); one core, then the same
@@ -89,15 +150,17 @@ def cpu_baseline_main(path):
                               f"P = {procs} processes; this box exposes {os.cpu_count()} CPUs)"))))
 
 
-def run_cpu_baseline(blocks_h, cb_h):
+def run_cpu_baseline(blocks_h, cb_h, leg="encode"):
+    """leg: "encode" (encode + decode, the headline metric), "lbg" (one LBG iteration) or "sample" (encode only, other
+    shapes).  Returns (the child's JSON, labels or new codebook as numpy)."""
     with tempfile.TemporaryDirectory() as tmp:
         path = os.path.join(tmp, "cpu_sample.npz")
         np.savez(path, blocks=blocks_h, cb=cb_h)
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-file", path],
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-file", path, "--cpu-leg", leg],
                              check=True, capture_output=True, text=True)
         base = json.loads(out.stdout.strip().splitlines()[-1])
-        labels = np.load(path + ".labels.npy")
-    return base, labels
+        extra = np.load(path + (".newcb.npy" if leg == "lbg" else ".labels.npy"))
+    return base, extra
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -142,7 +205,7 @@ def _nbytes_sorted(eng, d, N):
     return _lib.lib.vq_sorted_bytes(int(d), int(N))
 
 
-def search_profile(eng, img, bh, bw, cb, reps, device):
+def search_profile(eng, img, bh, bw, cb, reps, device, check_vectors=1 << 18):
     """Timings and statistics of the search on one (image, codebook): the filter kernel alone (HIP events on
     its stream), the fix-up alone, the evaluated share of all (vector, codeword) pairs."""
     import torch
@@ -160,7 +223,8 @@ def search_profile(eng, img, bh, bw, cb, reps, device):
     kw = dict(labels=labels, sorted=srt, shape=(N, d))
     for _ in range(2):
         eng.encode_prepared(blocks, prepared, **kw)
-    filter_ms = event_ms(lambda: eng.encode_prepared(blocks, prepared, phases=1, **kw), reps, device)
+    # the filter kernel alone: HIP events recorded by the library right around that launch, on its stream
+    filter_ms = eng.search_kernel_ms(lambda: eng.encode_prepared(blocks, prepared, phases=1, **kw), reps)
     queued, pairs_eval = eng.search_statistics(prepared, N)
     in_filter = bool(pruned and eng.prune_resolves_in_filter(K, d))     # near-ties settled inside the filter kernel
     fixup_ms = 0.0 if in_filter else event_ms(lambda: eng.encode_prepared(blocks, prepared, phases=2, **kw), reps, device)
@@ -169,6 +233,14 @@ def search_profile(eng, img, bh, bw, cb, reps, device):
     prep_ms = event_ms(lambda: eng.prepare_codebook(cb, 0), reps, device)
     e2e_scratch = torch.empty(max(int(_nbytes_sorted(eng, d, N)), N * d, 16), dtype=torch.uint8, device=device)
     e2e_ms = event_ms(lambda: eng.encode_image(img, bh, bw, cb, scratch=e2e_scratch, labels=labels), reps, device)
+    # labels against the all-fp64 search (every distance in sequential fp64 on the device) on a sample of the vectors
+    from vector_quantization_amd import VQ_MODE_EXACT
+    eng.encode_prepared(blocks, prepared, **kw)
+    bl = blocks if blocks is not None else eng.blocks_from_image(img, bh, bw)
+    ns = min(N, check_vectors)
+    labels_equal = bool(torch.equal(eng.encode(bl[:ns], cb, mode=VQ_MODE_EXACT), labels[:ns]))
+    if blocks is None:
+        del bl
     pairs_all = float(N) * K
     pairs_eval = float(pairs_eval)
     ops_exec = 2.0 * d * pairs_eval
@@ -180,7 +252,8 @@ def search_profile(eng, img, bh, bw, cb, reps, device):
                evaluated_pair_frac=pairs_eval / pairs_all,
                executed_tops=ops_exec / (filter_ms * 1e-3) / 1e12,
                frac_of_sad_ceiling=ops_exec / (filter_ms * 1e-3) / 1e12 / PEAK_SAD_TOPS,
-               algorithmic_tops=2.0 * d * pairs_all / (filter_ms * 1e-3) / 1e12)
+               algorithmic_tops=2.0 * d * pairs_all / (filter_ms * 1e-3) / 1e12,
+               labels_equal=labels_equal, labels_checked=f"first {ns} vectors against the all-fp64 search")
     return out, labels, srt, prepared, blocks
 
 
@@ -192,9 +265,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1 << 22, help="block vectors timed on the host (0 = skip)")
     ap.add_argument("--no-shapes", action="store_true", help="skip the other-shape and full-training measurements")
     ap.add_argument("--cpu-baseline-file", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-leg", default="encode", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_file:
-        cpu_baseline_main(args.cpu_baseline_file)
+        {"encode": cpu_baseline_main, "lbg": cpu_lbg_main, "sample": cpu_encode_sample_main}[args.cpu_leg](args.cpu_baseline_file)
         return
 
     import torch
@@ -260,7 +334,7 @@ def main():
     # the measure of what pruning saves
     blocks = eng.blocks_from_image(img, BH, BW)
     lab_full = torch.empty_like(labels)
-    full_ms = event_ms(lambda: eng.encode_prepared(blocks, prepared, labels=lab_full, phases=1), reps, device)
+    full_ms = eng.search_kernel_ms(lambda: eng.encode_prepared(blocks, prepared, labels=lab_full, phases=1), reps)
     _, pairs_full = eng.search_statistics(prepared, N)
     eng.encode_prepared(blocks, prepared, labels=lab_full)
     full_equals_pruned = bool(torch.equal(lab_full, labels_step))
@@ -274,17 +348,17 @@ def main():
     # from the same libvqhip.so is committed under profiles/ (FETCH_SIZE doubled per the gfx950 correction)
     traffic, pmc_note = None, "no PMC summary for this library build under profiles/"
     lib_sha = hashlib.sha256(open(_lib.library_path(), "rb").read()).hexdigest()[:16]
-    pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
     pmc = None
     if os.path.isfile(pmc_path):
         with open(pmc_path) as f:
             pmc = json.load(f)
         if pmc.get("library_sha256_16") != lib_sha:
-            pmc_note = (f"profiles/r02_pmc_summary.json was made from library {pmc.get('library_sha256_16')}, this run "
+            pmc_note = (f"profiles/r03_pmc_summary.json was made from library {pmc.get('library_sha256_16')}, this run "
                         f"uses {lib_sha}: not reported")
             pmc = None
         else:
-            pmc_note = "HBM traffic per launch from profiles/r02_pmc_*.csv (rocprofv3 --pmc passes of this library build)"
+            pmc_note = "HBM traffic per launch from profiles/r03_pmc_*.csv (rocprofv3 --pmc passes of this library build)"
 
     def pmc_bytes(role):
         r = (pmc or {}).get("roles", {}).get(role)
@@ -292,8 +366,8 @@ def main():
 
     traffic = pmc_bytes("search_filter")
     roofline = dict(
-        bound="valu", unit="TFLOP/s",
-        kernel="k_assign_fast<DP2=8, R=4, packed keys, scalar-load codewords, PRUNE> (the filter launch of "
+        bound="valu", unit="Tops/s (integer subtract and |.|-accumulate operations)",
+        kernel="k_assign_fast<DP2=8, R=2, packed keys, scalar-load codewords, PRUNE> (the filter launch of "
                "vq_encode_l1_prepared / vq_encode_l1_img on window-sorted vectors)",
         kernel_ms=prof["filter_kernel_ms"],
         achieved=prof["executed_tops"], peak=PEAK_SAD_TOPS, frac=prof["frac_of_sad_ceiling"], traffic=traffic,
@@ -308,11 +382,11 @@ def main():
         full_search_labels_equal=full_equals_pruned, step_labels_equal_profiled=step_labels_equal,
         note="L1 distance has no GEMM form, so the bound is the vector ALU, not MFMA or HBM. achieved = EXECUTED "
              "subtract + |.|-accumulate ops (2*d per evaluated (vector, codeword) pair; pairs counted by the kernel "
-             "itself: rows each wave evaluated x its 256 vectors) / the filter kernel's mean duration (HIP events "
-             "around that launch alone). peak = the v_sad_u16 issue ceiling: one wave64 instruction per 4 cycles per "
-             "SIMD (measured, profiles/r02_valu_ubench_forms1.txt and _forms2.txt; no operand form issues faster), two |x-c| accumulations "
+             "itself: rows each wave evaluated x its 128 vectors) / the filter kernel's mean duration (HIP events "
+             "recorded by the library right around that launch, on its stream). peak = the v_sad_u16 issue ceiling: one wave64 instruction per 4 cycles per "
+             "SIMD (measured, profiles/r02_valu_ubench_forms1.txt and _forms2.txt, column ms; no operand form issues faster), two |x-c| accumulations "
              "per lane = 157.3 T ops/s. Besides its d/2 SADs every pair costs 3 more instructions of the same issue "
-             "class (key, median, minimum), so 8/11 = 0.73 is the ceiling of frac at d = 16; the kernel's time also "
+             "class per codeword pair (two keys, median, min3, min: 2.5 per codeword), so 8/10.5 = 0.76 is the ceiling of frac at d = 16; the kernel's time also "
              "holds the fp64 re-check of its near-ties (queued_for_fp64_frac of the vectors; there is no fix-up "
              "launch for this shape, fixup_kernel_ms = 0). The pruned search "
              "evaluates only evaluated_pair_frac of all N*K pairs (codewords whose element sum differs from the "
@@ -341,10 +415,10 @@ def main():
 
     def lbg_run(cur, steps):
         if distributed:
-            for _ in range(steps):
-                # the vectors do not change between iterations: the sort made above serves all of them
-                cur, _ = lbg_iteration(eng, blocks, cur, n_total, group, shard_info, sorted=srt)
-            return cur
+            # several GPUs: the same stage with the exchange of every iteration enqueued between its two halves, on
+            # device tensors (nothing returns to the host but the 16-byte records)
+            aligned, sizes = shard_info
+            return eng.lbg_stage_group(blocks, cur, n_total, -1.0, steps, group, sizes, aligned, sorted=srt)[0]
         # one GPU: what train_lbg runs -- a stage of `steps` iterations with the stop rule on the device
         # (threshold < 0: it never holds), iteration j + 1 enqueued before the outcome of iteration j is read
         return eng.lbg_stage(blocks, cur, n_total, -1.0, steps, sorted=srt)[0]
@@ -359,9 +433,25 @@ def main():
     if distributed:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     lbg_elapsed = float(t.item())
-    lbg = {"iters_per_s": lbg_steps / lbg_elapsed, "vectors_per_s": n_total * lbg_steps / lbg_elapsed,
+    # the dominant kernel of an iteration alone: the pruned search with the per-cluster accumulation and the winners'
+    # fp64 distances fused in (HIP events recorded by the library around that launch)
+    acc_ms = eng.search_kernel_ms(lambda: eng.lbg_accum(None, cb, sorted=srt, shape=(N, d)), 20)
+    _, acc_pairs = eng.search_statistics((cb, eng._workspace(K_CODEBOOK, d, N)), N)
+    acc_ops = (2.0 * d) * float(acc_pairs) + float(d) * N        # SAD work of the evaluated pairs + d byte sums per vector
+    lbg_roofline = dict(
+        bound="valu", unit="Tops/s (integer subtract and |.|-accumulate operations)",
+        kernel="k_assign_fast<DP2=8, R=2, packed keys, scalar-load codewords, PRUNE, ACC> (vq_lbg_iterate / vq_lbg_accum)",
+        kernel_ms=acc_ms, achieved=acc_ops / (acc_ms * 1e-3) / 1e12, peak=PEAK_SAD_TOPS,
+        frac=acc_ops / (acc_ms * 1e-3) / 1e12 / PEAK_SAD_TOPS, traffic=pmc_bytes("lbg_assign"),
+        algorithmic_ops_per_vector=2 * K_CODEBOOK * d + d, algorithmic_bytes_per_vector=d,
+        evaluated_pair_frac=float(acc_pairs) / (float(N) * K_CODEBOOK),
+        note="executed ops = 2*d per evaluated (vector, codeword) pair + d accumulations per vector, against the v_sad_u16 "
+             "issue ceiling; besides the search the kernel adds every vector's bytes into an LDS table (staged, "
+             "transposed 64-bit LDS atomics) and evaluates the winner's fp64 distance from an LDS copy of the codebook")
+    lbg = {"iters_per_s": lbg_steps / lbg_elapsed, "roofline": lbg_roofline, "vectors_per_s": n_total * lbg_steps / lbg_elapsed,
            "ms_per_iter": lbg_elapsed / lbg_steps * 1e3, "vectors_total": n_total, "timed_iterations": lbg_steps,
-           "exchange": ("one collective per iteration on int64 [K*d sums | K counts] + fp64 per-chunk distance sums"
+           "exchange": ("one collective per iteration on int64 [K*d sums | K counts] + fp64 per-chunk distance sums, "
+                        "enqueued on device tensors between vq_lbg_iterate_local and vq_lbg_iterate_finish"
                         if distributed else "none (1 GPU)")}
 
     result = {
@@ -435,6 +525,29 @@ def main():
         base, cpu_labels = run_cpu_baseline(blocks[:n_s].cpu().numpy(), cb.cpu().numpy())
         result["cpu_baseline"] = base
         result["cpu_labels_match_gpu"] = bool(np.array_equal(cpu_labels, labels_step[:n_s].cpu().numpy().astype(np.int64)))
+        # the other half of the metric: one LBG iteration of the reference arithmetic on 2^20 of the vectors, with the
+        # GPU's iteration on the same vectors beside it (codebooks compared bit for bit)
+        n_l = min(1 << 20, n_s)
+        lb, cpu_cb = run_cpu_baseline(blocks[:n_l].cpu().numpy(), cb.cpu().numpy(), leg="lbg")
+        gpu_cb, gpu_D = lbg_iteration(eng, blocks[:n_l].contiguous(), cb, n_l)
+        lb["codebook_equals_gpu"] = bool(np.array_equal(cpu_cb, gpu_cb.cpu().numpy()))
+        lb["distortion_equals_gpu"] = bool(lb["distortion"] == gpu_D)
+        lb["note"] = ("iterations/s at the full workload = value / vectors_per_gpu (the arithmetic is linear in the "
+                      "number of vectors)")
+        lb["iterations_per_s_at_workload"] = lb["value"] / N
+        base["lbg"] = lb
+        if not args.no_shapes:
+            # encode-only figures for the codebook shapes of configs[2] and configs[4] on samples (one core)
+            samples = {}
+            for name, cbx, n_x in (("K1024_d16", cb1k, 1 << 18),):
+                sb, sl = run_cpu_baseline(blocks[:n_x].cpu().numpy(), cbx.cpu().numpy(), leg="sample")
+                sb["labels_equal_gpu"] = bool(np.array_equal(sl, eng.encode(blocks[:n_x], cbx).cpu().numpy().astype(np.int64)))
+                samples[name] = sb
+            b192 = eng.blocks_from_image(structured_image(1024, 1024, 5, device, channels=3), 8, 8)[:8192].contiguous()
+            sb, sl = run_cpu_baseline(b192.cpu().numpy(), cb192.cpu().numpy(), leg="sample")
+            sb["labels_equal_gpu"] = bool(np.array_equal(sl, eng.encode(b192, cb192).cpu().numpy().astype(np.int64)))
+            samples["cfg5_K4096_d192"] = sb
+            base["other_shapes"] = samples
     else:
         result["cpu_baseline"] = None
 

@@ -11,8 +11,10 @@
  *   - Return value: 0 on success, a negative VQ_E_* code on failure; vq_last_error()
  *     returns a thread-local message for the last failure on the calling thread.
  *   - The library may be called from any host thread.  The only state it keeps between calls are
- *     three mutex-guarded tables: device properties (queried once per device), the buffers
- *     vq_blocks_sort has filled (address -> N, d), and the per-device address of the static scratch.
+ *     three mutex-guarded tables -- device properties (queried once per device), the buffers
+ *     vq_blocks_sort has filled (address -> N, d; at most 4096 records, see vq_sorted_forget), the
+ *     per-device address of the static scratch -- and, per host thread, a note of what the last
+ *     vq_lbg_iterate / vq_lbg_iterate_local left in a workspace (see there).
  *   - Block vectors are rows of an (N, d) uint8 matrix, d = block_h * block_w * C, element
  *     order (row-in-block, col-in-block, channel), vectors in row-major block-grid order.
  *     Codebooks are (K, d) IEEE doubles, row-major.
@@ -82,7 +84,10 @@ int vq_encode_l1(const uint8_t *blocks, int64_t N, int d, const double *cb, int 
  * call allocates nothing.  A (K, d, N) whose vq_workspace_bytes exceeds that size is refused with
  * VQ_E_UNSUPPORTED (at K = 256, d = 16 about 1.7 million vectors per call fit).  Every call on a GPU
  * shares that GPU's array: calls that overlap in time on one GPU (different streams or threads)
- * race on it and must be serialised by the caller. */
+ * race on it and must be serialised by the caller.  The first call on a device looks the array's address up
+ * (hipGetSymbolAddress) and a first call per kernel shape may set a function attribute: make one warm-up
+ * call per device and shape outside any stream capture (vq_static_scratch_bytes() does the address
+ * look-up for the current device as well). */
 size_t vq_static_scratch_bytes(void);
 int vq_encode_l1_static(const uint8_t *blocks, int64_t N, int d, const double *cb, int K,
                         int32_t *labels, double *min_dist, int mode, void *stream);
@@ -100,8 +105,12 @@ int vq_encode_l1_static(const uint8_t *blocks, int64_t N, int d, const double *c
  * filled for which (N, d).  A search that is handed a `sorted` argument it has no such record of, one
  * recorded for another N or d, or one smaller than vq_sorted_bytes(d, N), returns VQ_E_INVALID; a
  * buffer whose header was overwritten since the sort makes the search write label -1 for every
- * vector instead of following a stale origin map. */
+ * vector instead of following a stale origin map.  The record is keyed by the buffer's address: a copy of a
+ * sorted buffer is not accepted (sort into the copy), and before a sorted buffer's memory is freed or reused
+ * for something else the caller should drop its record with vq_sorted_forget (returns 1 if there was one);
+ * the table holds at most 4096 records and starts over when it is full (a search then asks for a fresh sort). */
 size_t vq_sorted_bytes(int d, int64_t N);
+int vq_sorted_forget(const void *sorted);
 int vq_prune_supported(int K, int d);
 int vq_blocks_sort(const uint8_t *blocks, int64_t N, int d, void *sorted, size_t sorted_bytes, void *stream);
 
@@ -144,6 +153,11 @@ int vq_encode_l1_prepared_phases(const uint8_t *blocks, const void *sorted, size
                                  const double *cb, int K, int32_t *labels, double *min_dist, int phases, void *ws,
                                  size_t ws_bytes, void *stream);
 size_t vq_workspace_counters_offset(int K, int d, int64_t N);
+/* For profiling and benchmarks: the next launch of the search kernel (the filter of VQ_MODE_FAST, with or without the
+ * fused LBG accumulation) made by the calling thread is bracketed by hipEventRecord(ev_start) / hipEventRecord(ev_stop)
+ * on the call's stream -- that kernel alone, whatever else the entry point enqueues.  One-shot; two hipEvent_t handles
+ * created with timing enabled (null, null cancels). */
+void vq_profile_next_search(void *ev_start, void *ev_stop);
 /* 1 when the pruned search of a (K, d) codebook (vq_prune_supported, `sorted` given) settles its near-ties inside
  * the filter kernel, so that its phase 2 launches nothing; 0 when it queues them for the fix-up kernel. */
 int vq_prune_resolves_in_filter(int K, int d);
@@ -173,9 +187,11 @@ int vq_lbg_accum(const uint8_t *blocks, const void *sorted, size_t sorted_bytes,
  * i: once an iteration has met the rule, the kernels of later iterations of that stage return at once
  * and leave cb and the records untouched.  Record i sits at byte 64 + 16 * i of the state:
  * { double distortion; uint32 converged; uint32 valid } -- valid = 0 marks an iteration that was skipped.
- * A negative threshold never converges (forced iteration counts).  Consecutive iterations of a stage that use
- * the same ws and state, with no other entry point given that ws in between, skip re-zeroing the tables of ws
- * (the previous iteration leaves them zeroed); any other call sequence is detected and costs one extra fill. */
+ * A negative threshold never converges (forced iteration counts).  Consecutive iterations of a stage issued by ONE
+ * host thread with the same ws, state, N, K and d, and no other entry point given that ws by that thread in between,
+ * skip re-zeroing the tables of ws (the previous iteration leaves them zeroed); any other call sequence of that
+ * thread costs one extra fill.  The note is per host thread: a workspace must not be shared between host threads,
+ * nor written by the caller, while a stage runs. */
 /* 1 when vq_lbg_iterate in VQ_MODE_FAST with a `sorted` buffer runs this (K, d) as one fused pass (search and
  * accumulation in one kernel): labels may then be null (none are written, which saves their stores during
  * training) and min_dist is scratch whose contents are unspecified afterwards.  0: labels is required. */
@@ -185,6 +201,26 @@ int vq_lbg_stage_begin(void *state, size_t state_bytes, int max_iterations, void
 int vq_lbg_iterate(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d, double *cb, int K,
                    int64_t n_total, double threshold, int iteration, uint64_t *sums, uint64_t *counts, int32_t *labels,
                    double *min_dist, int mode, void *state, size_t state_bytes, void *ws, size_t ws_bytes, void *stream);
+
+/* The same iteration for block vectors sharded over several GPUs (one process per GPU), split around the exchange so
+ * that nothing returns to the host.  No counterpart in the reference (VQ_Full.py:76-98 is one process).
+ * vq_lbg_iterate_local: this rank's part of VQ_Full.py:77-90 -- sums / counts of its N vectors (overwritten),
+ * chunk_sums[0 .. ceil(N / 8192)) = the per-chunk sums of its winning distances (ceil(N / 8192) + 1 doubles of
+ * room), local_total[0] = their left-to-right total.  vq_lbg_iterate_finish: given the sums / counts added over all
+ * ranks and every rank's chunk sums (rank r's h_chunk_counts[r] <= width values at chunk_sums_all[r * width]; device
+ * memory, e.g. the output of an all-gather; world <= 64), adds the chunk sums left to right in rank order -- bit for
+ * bit the single-process distance sum when every rank but the last holds a multiple of 8192 vectors; ranks whose
+ * shards are not aligned pass their local_total as a single value -- then updates cb in place and applies the stop
+ * rule for `iteration` exactly as vq_lbg_iterate does.  Both calls carry the stage's gate: enqueued for an
+ * iteration past the one that converged they leave cb and the records untouched (the collectives between them
+ * still run, on every rank alike).  labels as in vq_lbg_iterate (nullable when vq_lbg_pass_fused). */
+int vq_lbg_iterate_local(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d, const double *cb,
+                         int K, int iteration, uint64_t *sums, uint64_t *counts, double *chunk_sums, double *local_total,
+                         int32_t *labels, double *min_dist, int mode, void *state, size_t state_bytes, void *ws,
+                         size_t ws_bytes, void *stream);
+int vq_lbg_iterate_finish(const uint64_t *sums, const uint64_t *counts, const double *chunk_sums_all, int world, int width,
+                          const int *h_chunk_counts, double *cb, int K, int d, int64_t n_total, double threshold,
+                          int iteration, void *state, size_t state_bytes, void *stream);
 
 /* Sum of an fp64 vector in the order numpy.add.reduce uses on a contiguous array (what np.mean
  * does before dividing, VQ_Full.py:90): pairwise summation -- runs of up to 128 elements with

@@ -121,11 +121,44 @@ def _nccl_one_gpu_worker(rank, world, port, out_dir):
         blocks = torch.from_numpy(_make_blocks()).to("cuda:0")
         eng = HipEngine("cuda:0")
         out = {}
-        for name, thr in (("gather", 1 << 40), ("allreduce", 0)):
-            lbg_mod.ALLREDUCE_FROM_BYTES = thr
-            res = train_lbg(eng, blocks, 32, group=dist.group.WORLD, log=None)
-            out[name + "_cb"] = res.codebook.cpu().numpy()
-            out[name + "_dist"] = np.array(res.distortions)
+        # every stage must go through the device-resident form, and that form must not come back to the host: no
+        # Tensor.cpu / item / tolist and no device-wide synchronisation between a stage's first enqueue and its last
+        # record (the records are read through a side stream that waits on events only)
+        calls = {"stage": 0, "host": 0}
+        inner = eng.lbg_stage_group
+
+        def counting(name, fn):
+            def wrapped(*a, **k):
+                if calls["stage_open"]:
+                    calls["host"] += 1
+                return fn(*a, **k)
+            return wrapped
+
+        def stage(*a, **k):
+            calls["stage"] += 1
+            calls["stage_open"] = True
+            try:
+                return inner(*a, **k)
+            finally:
+                calls["stage_open"] = False
+
+        calls["stage_open"] = False
+        eng.lbg_stage_group = stage
+        saved = (torch.Tensor.cpu, torch.Tensor.item, torch.Tensor.tolist, torch.cuda.synchronize)
+        torch.Tensor.cpu = counting("cpu", saved[0])
+        torch.Tensor.item = counting("item", saved[1])
+        torch.Tensor.tolist = counting("tolist", saved[2])
+        torch.cuda.synchronize = counting("synchronize", saved[3])
+        try:
+            for name, thr in (("gather", 1 << 40), ("allreduce", 0)):
+                lbg_mod.ALLREDUCE_FROM_BYTES = thr
+                res = train_lbg(eng, blocks, 32, group=dist.group.WORLD, log=None)
+                out[name + "_cb"] = res.codebook.cpu().numpy()
+                out[name + "_dist"] = np.array(res.distortions)
+        finally:
+            torch.Tensor.cpu, torch.Tensor.item, torch.Tensor.tolist, torch.cuda.synchronize = saved
+        out["stages"] = np.array(calls["stage"])
+        out["host_calls"] = np.array(calls["host"])
         np.savez(os.path.join(out_dir, "nccl1.npz"), **out)
     finally:
         dist.destroy_process_group()
@@ -139,6 +172,95 @@ def test_rccl_exchange_world_size_one(tmp_path, oracle):
     for name in ("gather", "allreduce"):
         assert np.array_equal(r[name + "_cb"], ref["codebook"])
         assert np.array_equal(r[name + "_dist"], ref["distortions"])
+    assert int(r["stages"]) == 2 * 5                    # K = 32: five split stages per training, all device-resident
+    assert int(r["host_calls"]) == 0
+
+
+def _p(t):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+@pytest.mark.parametrize("cuts", [(8192, 2 * 8192), (8192, 8192), (5000, 20000), (0, 3 * 8192)])
+@pytest.mark.parametrize("K", [32, 64])
+def test_iterate_local_and_finish_equal_one_process(cuts, K, oracle):
+    """vq_lbg_iterate_local on three shards (one GPU, one after the other, each with its own workspace and state),
+    the exchange done by hand (sums added, chunk sums laid out rank by rank), vq_lbg_iterate_finish on every
+    "rank": codebook and distortion record equal vq_lbg_iterate on all vectors -- bit for bit when the shards are
+    8192-aligned -- and the CPU oracle's iteration.  Covers an empty shard and shards that are not aligned."""
+    import ctypes
+    from vector_quantization_amd import HipEngine
+    from vector_quantization_amd._lib import lib, check
+    dev = torch.device("cuda:0")
+    eng = HipEngine(dev)
+    blocks_h = _make_blocks()
+    N, d = blocks_h.shape
+    rng = np.random.default_rng(5)
+    cb_h = np.clip(blocks_h[rng.choice(N, K, replace=False)].astype(np.float64) + rng.normal(0, 0.3, (K, d)), 0, 255)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    bounds = [0, cuts[0], cuts[1], N]
+    sizes = [bounds[i + 1] - bounds[i] for i in range(3)]
+    aligned = all(n % 8192 == 0 for n in [s for s in sizes if s > 0][:-1])
+
+    def state_buf():
+        n = lib.vq_lbg_state_bytes(4)
+        st = torch.empty(n, dtype=torch.uint8, device=dev)
+        check(lib.vq_lbg_stage_begin(_p(st), n, 4, stream), "stage_begin")
+        return st, n
+
+    # the single-process iteration
+    blocks = torch.from_numpy(blocks_h).to(dev)
+    srt = eng.sort_blocks(blocks)
+    cb1 = torch.from_numpy(cb_h).to(dev)
+    st1, nst = state_buf()
+    acc1 = torch.empty(K * d + K, dtype=torch.int64, device=dev)
+    dist1 = torch.empty(N, dtype=torch.float64, device=dev)
+    ws1 = torch.empty(lib.vq_workspace_bytes(K, d, N), dtype=torch.uint8, device=dev)
+    check(lib.vq_lbg_iterate(None, _p(srt), srt.numel(), N, d, _p(cb1), K, N, 0.001, 0, _p(acc1[:K * d]), _p(acc1[K * d:]),
+                             None, _p(dist1), 1, _p(st1), nst, _p(ws1), ws1.numel(), stream), "vq_lbg_iterate")
+    # the sharded iteration
+    width = max(1, max(-(-n // 8192) for n in sizes)) if aligned else 1
+    accs, tails = [], []
+    for r in range(3):
+        n = sizes[r]
+        sh = blocks[bounds[r]:bounds[r + 1]].contiguous()
+        srt_r = eng.sort_blocks(sh) if n else None
+        cb_r = torch.from_numpy(cb_h).to(dev)
+        st_r, _ = state_buf()
+        acc = torch.empty(K * d + K, dtype=torch.int64, device=dev)
+        chunk = torch.zeros(-(-n // 8192) + 1, dtype=torch.float64, device=dev)
+        total = torch.zeros(1, dtype=torch.float64, device=dev)
+        dist_r = torch.empty(max(n, 1), dtype=torch.float64, device=dev)
+        lab_r = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        ws = torch.empty(lib.vq_workspace_bytes(K, d, n), dtype=torch.uint8, device=dev)
+        check(lib.vq_lbg_iterate_local(_p(sh) if n else None, _p(srt_r), srt_r.numel() if n else 0, n, d, _p(cb_r), K, 0,
+                                       _p(acc[:K * d]), _p(acc[K * d:]), _p(chunk), _p(total), _p(lab_r), _p(dist_r), 1,
+                                       _p(st_r), nst, _p(ws), ws.numel(), stream), "vq_lbg_iterate_local")
+        accs.append(acc)
+        t = torch.zeros(width, dtype=torch.float64, device=dev)
+        if aligned:
+            t[: -(-n // 8192)] = chunk[: -(-n // 8192)]
+        else:
+            t[0] = total[0]
+        tails.append(t)
+    acc_total = torch.stack(accs).sum(dim=0)
+    chunks_all = torch.stack(tails).contiguous()
+    counts = (ctypes.c_int * 3)(*[(-(-n // 8192) if aligned else 1) for n in sizes])
+    cb2 = torch.from_numpy(cb_h).to(dev)
+    st2, _ = state_buf()
+    check(lib.vq_lbg_iterate_finish(_p(acc_total[:K * d]), _p(acc_total[K * d:]), _p(chunks_all), 3, width, counts, _p(cb2),
+                                    K, d, N, 0.001, 0, _p(st2), nst, stream), "vq_lbg_iterate_finish")
+    torch.cuda.synchronize(dev)
+    assert torch.equal(acc_total, acc1)
+    assert torch.equal(cb2, cb1)
+    rec1 = st1[64:80].cpu().numpy().view(np.float64)[0]
+    rec2 = st2[64:80].cpu().numpy().view(np.float64)[0]
+    if aligned:
+        assert rec1 == rec2
+    else:
+        assert np.isclose(rec1, rec2, rtol=1e-12, atol=0)
+    ref = oracle.lbg_iter(blocks_h, cb_h)
+    assert np.array_equal(cb1.cpu().numpy(), ref["cb_out"]) and rec1 == ref["distortion"]
 
 
 def _batch_images(n_images=16, side=512):

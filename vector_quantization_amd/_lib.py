@@ -20,7 +20,7 @@ VQ_MODE_FAST = 1
 VQ_PAD_EDGE = 0
 VQ_PAD_ZERO = 1
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -48,11 +48,15 @@ SIGNATURES = {
     "vq_encode_l1_prepared": (_i, [_vp, _vp, _sz, _i64, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "vq_encode_l1_prepared_phases": (_i, [_vp, _vp, _sz, _i64, _i, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp]),
     "vq_workspace_counters_offset": (_sz, [_i, _i, _i64]),
+    "vq_profile_next_search": (None, [_vp, _vp]),
     "vq_lbg_accum": (_i, [_vp, _vp, _sz, _i64, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "vq_lbg_pass_fused": (_i, [_i, _i]),
     "vq_lbg_state_bytes": (_sz, [_i]),
     "vq_lbg_stage_begin": (_i, [_vp, _sz, _i, _vp]),
     "vq_lbg_iterate": (_i, [_vp, _vp, _sz, _i64, _i, _vp, _i, _i64, _dbl, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _sz, _vp]),
+    "vq_lbg_iterate_local": (_i, [_vp, _vp, _sz, _i64, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _sz, _vp]),
+    "vq_lbg_iterate_finish": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i64, _dbl, _i, _vp, _sz, _vp]),
+    "vq_sorted_forget": (_i, [_vp]),
     "vq_numpy_sum_f64": (_i, [_vp, _i64, _vp, _vp, _vp]),
     "vq_accum_labels": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp, _vp]),
     "vq_lbg_finalize": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),

@@ -84,7 +84,7 @@ int fail(int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(VQ_E_HIP, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
     } while (0)
 
-constexpr int ABI_VERSION = 5;
+constexpr int ABI_VERSION = 6;
 constexpr int WAVE = 64;
 constexpr int64_t NP_CHUNK = 8192;      // numpy's reduction buffer: elements per pairwise-summed chunk
 constexpr int MAX_D_FAST = 192;         // largest vector dimension of the SAD filter kernels
@@ -2046,8 +2046,10 @@ __global__ __launch_bounds__(ACC ? 1024 : 512) VQ_ASSIGN_ATTR void k_assign_fast
             constexpr int U = DP2 <= 8 ? (PRUNE ? VQ_UP : VQ_U8) : (DP2 <= 16 ? 2 : 1);
             // rows [lo, hi) of the fixed-point codebook, hi - lo a multiple of U (rows K .. Kpad are
             // pad rows that never win)
-            // The rows of the next trip are requested before this trip's arithmetic starts, so that the wave does
-            // not sit out a scalar-memory round trip per batch (the last trip re-reads its own rows).
+            // 16-byte rows in pairs (the pruned search at d <= 16): the rows of the next trip are requested before this
+            // trip's arithmetic starts, so that the wave does not sit out a scalar-memory round trip per batch (the
+            // last trip re-reads its own rows).  The compiler folds a rotated loop of plain loads back into load-and-wait,
+            // hence the explicit requests.
             auto run = [&](int lo, int hi) {
                 if (lo >= hi) return;                          // (wave-uniform)
                 if constexpr (DP2 == 8 && U == 2 && KEYMODE == KEY_PACKED) {
@@ -2073,30 +2075,20 @@ __global__ __launch_bounds__(ACC ? 1024 : 512) VQ_ASSIGN_ATTR void k_assign_fast
                     }
                     return;
                 }
-                uint32_t cw[U][DP2], b[U];
-                auto fetch = [&](uint32_t (*w)[DP2], uint32_t *bb, int k) {
+                for (int k = lo; k < hi; k += U) {
+                    uint32_t cw[U][DP2], b[U];
 #pragma unroll
                     for (int j = 0; j < U; ++j) {
 #pragma unroll
-                        for (int p = 0; p < DP2; ++p) w[j][p] = c16[(size_t)(k + j) * DP2 + p];
-                        bb[j] = bias[k + j];
+                        for (int p = 0; p < DP2; ++p) cw[j][p] = c16[(size_t)(k + j) * DP2 + p];
+                        b[j] = bias[k + j];
                     }
-                };
-                fetch(cw, b, lo);
-                for (int k = lo; k < hi; k += U) {
-                    uint32_t nw[U][DP2], nb[U];
-                    fetch(nw, nb, k + U < hi ? k + U : k);
-                    if constexpr (U == 2 && KEYMODE == KEY_PACKED) {
-                        step2(cw[0], cw[1], b[0], b[1]);
+                    if constexpr (U % 2 == 0 && KEYMODE == KEY_PACKED) {
+#pragma unroll
+                        for (int j = 0; j < U; j += 2) step2(cw[j], cw[j + 1], b[j], b[j + 1]);
                     } else {
 #pragma unroll
                         for (int j = 0; j < U; ++j) step(cw[j], b[j], k + j);
-                    }
-#pragma unroll
-                    for (int j = 0; j < U; ++j) {
-#pragma unroll
-                        for (int p = 0; p < DP2; ++p) cw[j][p] = nw[j][p];
-                        b[j] = nb[j];
                     }
                 }
             };
@@ -3243,6 +3235,45 @@ __global__ __launch_bounds__(1024) void k_lbg_finish(const double *__restrict__ 
     }
 }
 
+// The tail of an LBG iteration whose vectors are sharded over several ranks (one workgroup): the ranks' per-chunk
+// distance sums -- rank r's count[r] values at chunks_all[r * width] -- added left to right in rank order (what one
+// process computes on the concatenated vectors when every shard but the last is a whole number of chunks), then the
+// centroid update in place from the reduced sums / counts and the stop rule (VQ_Full.py:81-98).
+constexpr int MAX_RANKS = 64;
+struct RankChunks {
+    int world, width;
+    int count[MAX_RANKS];
+};
+__global__ __launch_bounds__(1024) void k_lbg_finish_ranks(const double *__restrict__ chunks_all, const RankChunks rc,
+                                                           const unsigned long long *__restrict__ sums,
+                                                           const unsigned long long *__restrict__ counts, double *cb, int K,
+                                                           int d, double n_total, double threshold, LbgState *state, Gate g) {
+    __shared__ double s_buf[1024];
+    if (gate_closed(g)) return;
+    double total = 0.0;
+    for (int r = 0; r < rc.world; ++r) {
+        const double *cs = chunks_all + (size_t)r * rc.width;
+        for (int lo = 0; lo < rc.count[r]; lo += 1024) {
+            const int i = lo + (int)threadIdx.x;
+            s_buf[threadIdx.x] = i < rc.count[r] ? cs[i] : 0.0;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int cnt = rc.count[r] - lo < 1024 ? rc.count[r] - lo : 1024;
+                for (int j = 0; j < cnt; ++j) total += s_buf[j];
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < K * d; i += 1024) {
+        const unsigned long long c = counts[i / d];
+        if (c) cb[i] = (double)sums[i] / (double)c;
+    }
+    if (threadIdx.x == 0) {
+        state->dist_sum = total;
+        apply_stop_rule(state, total, n_total, threshold, g.iter);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // nearest codeword, EXACT mode: every distance in sequential fp64, one vector per lane
 // ------------------------------------------------------------------------------------------------
@@ -3608,6 +3639,9 @@ constexpr int r_lds_for(int dp2) { return dp2 <= 32 ? 4 : 2; }
 // Pruned search: rows beyond 32 bytes take two vectors per lane (registers).
 constexpr int r_prune_for(int dp2) { return dp2 <= 16 ? VQ_RP : 2; }
 
+// Events to record around the next search-kernel launch of the calling thread (vq_profile_next_search; one-shot).
+thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
+
 template <int DP2, int KEYMODE, bool LDS_CW, bool PRUNE = false, bool ACC = false>
 int launch_assign_fast_t(const AssignArgs &a, const uint32_t *c16, const uint32_t *bias, int block, int grid,
                          size_t lds, hipStream_t st) {
@@ -3616,8 +3650,12 @@ int launch_assign_fast_t(const AssignArgs &a, const uint32_t *c16, const uint32_
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
+    const hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
+    g_prof_start = g_prof_stop = nullptr;
+    if (ev0) HIP_TRY(hipEventRecord(ev0, st));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, st, a, c16, bias, a.cb);
     LAUNCH_CHECK("k_assign_fast");
+    if (ev1) HIP_TRY(hipEventRecord(ev1, st));
     return VQ_OK;
 }
 
@@ -3748,11 +3786,12 @@ struct TailLeft {
     const void *ws;
     const void *state;
     int iteration, K, d;
+    int64_t N;
 };
-thread_local TailLeft g_tail_left = {nullptr, nullptr, 0, 0, 0};
+thread_local TailLeft g_tail_left = {nullptr, nullptr, 0, 0, 0, 0};
 
 int check_ws(const void *ws, size_t ws_bytes, int K, int d, int64_t N) {
-    g_tail_left = TailLeft{nullptr, nullptr, 0, 0, 0};
+    g_tail_left = TailLeft{nullptr, nullptr, 0, 0, 0, 0};
     size_t need = ws_layout(K, d, N).total;
     if (!ws || ws_bytes < need) return fail(VQ_E_WORKSPACE, "workspace of %zu bytes needed, %zu given", need, ws_bytes);
     return VQ_OK;
@@ -3839,8 +3878,13 @@ struct SortedInfo {
 std::mutex g_sorted_mutex;
 std::unordered_map<uintptr_t, SortedInfo> g_sorted_known;
 
+constexpr size_t SORTED_KNOWN_CAP = 4096;                    // records kept; beyond that the table starts over
+
 void sorted_register(const void *sorted, int64_t N, int d, size_t bytes) {
     std::lock_guard<std::mutex> lock(g_sorted_mutex);
+    // a process that sorts ever new buffers and never calls vq_sorted_forget must not grow the table without bound:
+    // dropping records only makes a later search ask for a fresh sort (VQ_E_INVALID), never trust a stale one
+    if (g_sorted_known.size() >= SORTED_KNOWN_CAP) g_sorted_known.clear();
     g_sorted_known[reinterpret_cast<uintptr_t>(sorted)] = SortedInfo{N, d, bytes};
 }
 
@@ -4295,7 +4339,11 @@ int vq_encode_l1(const uint8_t *blocks, int64_t N, int d, const double *cb, int 
     return VQ_OK;
 }
 
-size_t vq_static_scratch_bytes(void) { return (size_t)VQ_STATIC_SCRATCH_BYTES; }
+size_t vq_static_scratch_bytes(void) {
+    void *p = nullptr;
+    (void)static_scratch(&p);                                  // look the current device's array up now (not under a capture later)
+    return (size_t)VQ_STATIC_SCRATCH_BYTES;
+}
 
 int vq_encode_l1_static(const uint8_t *blocks, int64_t N, int d, const double *cb, int K, int32_t *labels,
                         double *min_dist, int mode, void *stream) {
@@ -4526,14 +4574,22 @@ int vq_lbg_stage_begin(void *state, size_t state_bytes, int max_iterations, void
     return VQ_OK;
 }
 
-int vq_lbg_iterate(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d, double *cb, int K,
-                   int64_t n_total, double threshold, int iteration, uint64_t *sums, uint64_t *counts, int32_t *labels,
-                   double *min_dist, int mode, void *state, size_t state_bytes, void *ws, size_t ws_bytes, void *stream) {
+}  // extern "C"
+
+namespace {
+// One LBG iteration up to the per-rank results (finish = false: sums / counts of this call's vectors, their per-chunk
+// distance sums in chunk_out and the left-to-right total of those in total_out) or to the end (finish = true: centroid
+// update in place and stop rule as well, for one process holding all n_total vectors).
+int lbg_iterate_impl(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d, double *cb, int K,
+                     int64_t n_total, double threshold, int iteration, uint64_t *sums, uint64_t *counts, int32_t *labels,
+                     double *min_dist, int mode, void *state, size_t state_bytes, void *ws, size_t ws_bytes, void *stream,
+                     double *chunk_out, double *total_out, bool finish) {
     if (!state) return fail(VQ_E_INVALID, "null state pointer");
     if (iteration < 0 || state_bytes < vq_lbg_state_bytes(iteration + 1))
         return fail(VQ_E_INVALID, "iteration %d is outside the state buffer (%zu bytes)", iteration, state_bytes);
-    if (n_total < 1 || N > n_total) return fail(VQ_E_INVALID, "need n_total >= max(N, 1)");
+    if (finish && (n_total < 1 || N > n_total)) return fail(VQ_E_INVALID, "need n_total >= max(N, 1)");
     if (!sums || !counts || !cb) return fail(VQ_E_INVALID, "null sums, counts or codebook pointer");
+    if (!finish && (!chunk_out || !total_out)) return fail(VQ_E_INVALID, "null chunk_sums or local_total pointer");
     if (K <= 0 || d <= 0) return fail(VQ_E_INVALID, "need K > 0 and d > 0");
     hipStream_t st = static_cast<hipStream_t>(stream);
     LbgState *S = static_cast<LbgState *>(state);
@@ -4543,13 +4599,13 @@ int vq_lbg_iterate(const uint8_t *blocks, const void *sorted, size_t sorted_byte
     } scope(&S->stopped_after, iteration);
     // what the previous call on this thread left behind is read before check_ws forgets it
     const bool chained = g_tail_left.ws == ws && g_tail_left.state == state && g_tail_left.iteration + 1 == iteration &&
-                         g_tail_left.K == K && g_tail_left.d == d;
+                         g_tail_left.K == K && g_tail_left.d == d && g_tail_left.N == N;
     int rc = check_ws(ws, ws_bytes, K, d, N);
     if (rc) return rc;
     // The fused form: the search accumulates into the replica tables, k_lbg_fold and k_lbg_finish do the rest.
-    // The fold leaves the replica tables zeroed, so only the first iteration of a run of consecutive calls
-    // (same workspace, same state, iteration numbers counting up, no other call on the workspace in between)
-    // zeroes them.
+    // The fold leaves the replica tables zeroed, so only the first iteration of a run of consecutive calls made by
+    // one host thread (same workspace, same state, same N, iteration numbers counting up, no other call on the
+    // workspace in between) zeroes them.
     const bool fused = N > 0 && mode == VQ_MODE_FAST && fast_supported(d) && fused_acc_supported(sorted, K, d) &&
                        min_dist != nullptr;
     if (fused) {
@@ -4577,7 +4633,7 @@ int vq_lbg_iterate(const uint8_t *blocks, const void *sorted, size_t sorted_byte
         const int tabn = K * (d + 1);
         int64_t grid = nfull > (tabn + 511) / 512 ? nfull : (tabn + 511) / 512;
         if (grid > 4096) grid = 4096;
-        double *chunk_sums = reinterpret_cast<double *>(w + LN.chunks);
+        double *chunk_sums = chunk_out ? chunk_out : reinterpret_cast<double *>(w + LN.chunks);
         unsigned long long *s64 = reinterpret_cast<unsigned long long *>(sums);
         unsigned long long *c64 = reinterpret_cast<unsigned long long *>(counts);
         const uint16_t *perm = reinterpret_cast<const uint16_t *>(static_cast<const char *>(sorted) + sorted_layout(d, N).perm);
@@ -4587,10 +4643,16 @@ int vq_lbg_iterate(const uint8_t *blocks, const void *sorted, size_t sorted_byte
         hipLaunchKernelGGL(k_lbg_fold, dim3((unsigned)grid), dim3(512), fold_lds, st, min_dist, perm, nfull, chunk_sums,
                            reinterpret_cast<unsigned long long *>(w + L0.acc_rep), K, d, s64, c64, g_gate);
         LAUNCH_CHECK("k_lbg_fold");
-        hipLaunchKernelGGL(k_lbg_finish, dim3(1), dim3(1024), 0, st, min_dist, N, nfull, chunk_sums, s64, c64, cb, K, d,
-                           (double)n_total, threshold, S, g_gate);
-        LAUNCH_CHECK("k_lbg_finish");
-        g_tail_left = TailLeft{ws, state, iteration, K, d};
+        if (finish) {
+            hipLaunchKernelGGL(k_lbg_finish, dim3(1), dim3(1024), 0, st, min_dist, N, nfull, chunk_sums, s64, c64, cb, K, d,
+                               (double)n_total, threshold, S, g_gate);
+            LAUNCH_CHECK("k_lbg_finish");
+        } else {
+            // the trailing partial chunk and the total of this call's chunk sums
+            hipLaunchKernelGGL(k_npsum_final, dim3(1), dim3(1024), 0, st, min_dist, N, nfull, chunk_sums, total_out);
+            LAUNCH_CHECK("k_npsum_final");
+        }
+        g_tail_left = TailLeft{ws, state, iteration, K, d, N};
         return VQ_OK;
     }
     // one launch zeroes the caller's sums and counts, the queue counters and the replica tables of the workspace
@@ -4622,14 +4684,71 @@ int vq_lbg_iterate(const uint8_t *blocks, const void *sorted, size_t sorted_byte
             HIP_TRY(hipMemsetAsync(counts, 0, bytes[1], st));
         }
     }
-    rc = vq_lbg_accum(blocks, sorted, sorted_bytes, N, d, cb, K, sums, counts, labels, min_dist, &S->dist_sum, nullptr,
-                          mode, ws, ws_bytes, stream);
+    rc = vq_lbg_accum(blocks, sorted, sorted_bytes, N, d, cb, K, sums, counts, labels, min_dist,
+                      finish ? &S->dist_sum : total_out, chunk_out, mode, ws, ws_bytes, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_finalize_rule, dim3(grid_for((int64_t)K * d, 256, 4096)), dim3(256), 0, st,
-                       reinterpret_cast<const unsigned long long *>(sums),
-                       reinterpret_cast<const unsigned long long *>(counts), cb, K, d, (double)n_total, threshold, S, g_gate);
-    LAUNCH_CHECK("k_finalize_rule");
+    if (finish) {
+        hipLaunchKernelGGL(k_finalize_rule, dim3(grid_for((int64_t)K * d, 256, 4096)), dim3(256), 0, st,
+                           reinterpret_cast<const unsigned long long *>(sums),
+                           reinterpret_cast<const unsigned long long *>(counts), cb, K, d, (double)n_total, threshold, S, g_gate);
+        LAUNCH_CHECK("k_finalize_rule");
+    }
     return VQ_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int vq_lbg_iterate(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d, double *cb, int K,
+                   int64_t n_total, double threshold, int iteration, uint64_t *sums, uint64_t *counts, int32_t *labels,
+                   double *min_dist, int mode, void *state, size_t state_bytes, void *ws, size_t ws_bytes, void *stream) {
+    return lbg_iterate_impl(blocks, sorted, sorted_bytes, N, d, cb, K, n_total, threshold, iteration, sums, counts, labels,
+                            min_dist, mode, state, state_bytes, ws, ws_bytes, stream, nullptr, nullptr, true);
+}
+
+int vq_lbg_iterate_local(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d, const double *cb,
+                         int K, int iteration, uint64_t *sums, uint64_t *counts, double *chunk_sums, double *local_total,
+                         int32_t *labels, double *min_dist, int mode, void *state, size_t state_bytes, void *ws,
+                         size_t ws_bytes, void *stream) {
+    return lbg_iterate_impl(blocks, sorted, sorted_bytes, N, d, const_cast<double *>(cb), K, 0, 0.0, iteration, sums, counts,
+                            labels, min_dist, mode, state, state_bytes, ws, ws_bytes, stream, chunk_sums, local_total, false);
+}
+
+int vq_lbg_iterate_finish(const uint64_t *sums, const uint64_t *counts, const double *chunk_sums_all, int world, int width,
+                          const int *h_chunk_counts, double *cb, int K, int d, int64_t n_total, double threshold,
+                          int iteration, void *state, size_t state_bytes, void *stream) {
+    if (!state) return fail(VQ_E_INVALID, "null state pointer");
+    if (iteration < 0 || state_bytes < vq_lbg_state_bytes(iteration + 1))
+        return fail(VQ_E_INVALID, "iteration %d is outside the state buffer (%zu bytes)", iteration, state_bytes);
+    if (!sums || !counts || !cb || !chunk_sums_all || !h_chunk_counts) return fail(VQ_E_INVALID, "null pointer");
+    if (K <= 0 || d <= 0 || n_total < 1) return fail(VQ_E_INVALID, "need K > 0, d > 0, n_total >= 1");
+    if (world < 1 || world > MAX_RANKS) return fail(VQ_E_UNSUPPORTED, "world=%d is outside 1 .. %d", world, MAX_RANKS);
+    if (width < 1) return fail(VQ_E_INVALID, "need width >= 1");
+    RankChunks rcs;
+    rcs.world = world;
+    rcs.width = width;
+    for (int r = 0; r < MAX_RANKS; ++r) rcs.count[r] = 0;
+    for (int r = 0; r < world; ++r) {
+        if (h_chunk_counts[r] < 0 || h_chunk_counts[r] > width)
+            return fail(VQ_E_INVALID, "rank %d has %d chunk sums, the rows hold %d", r, h_chunk_counts[r], width);
+        rcs.count[r] = h_chunk_counts[r];
+    }
+    LbgState *S = static_cast<LbgState *>(state);
+    hipLaunchKernelGGL(k_lbg_finish_ranks, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), chunk_sums_all, rcs,
+                       reinterpret_cast<const unsigned long long *>(sums), reinterpret_cast<const unsigned long long *>(counts),
+                       cb, K, d, (double)n_total, threshold, S, Gate{&S->stopped_after, iteration});
+    LAUNCH_CHECK("k_lbg_finish_ranks");
+    return VQ_OK;
+}
+
+void vq_profile_next_search(void *ev_start, void *ev_stop) {
+    g_prof_start = static_cast<hipEvent_t>(ev_start);
+    g_prof_stop = static_cast<hipEvent_t>(ev_stop);
+}
+
+int vq_sorted_forget(const void *sorted) {
+    std::lock_guard<std::mutex> lock(g_sorted_mutex);
+    return g_sorted_known.erase(reinterpret_cast<uintptr_t>(sorted)) ? 1 : 0;
 }
 
 int vq_lbg_finalize(const uint64_t *sums, const uint64_t *counts, const double *cb_old, int K, int d, double *cb_new,

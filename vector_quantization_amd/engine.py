@@ -206,6 +206,22 @@ class HipEngine:
                                                    self._stream()), "vq_encode_l1_prepared_phases")
         return (labels, mind) if want_dist else labels
 
+    def search_kernel_ms(self, fn, reps=20):
+        """Mean duration in ms of the search kernel alone (HIP events recorded by the library right around that
+        launch, on the launch stream) over `reps` calls of fn(), each of which must launch it exactly once."""
+        stream = torch.cuda.current_stream(self.device)
+        pairs = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)                                   # (creates the handles)
+            b.record(stream)
+            lib.vq_profile_next_search(ctypes.c_void_p(a.cuda_event), ctypes.c_void_p(b.cuda_event))
+            fn()
+            pairs.append((a, b))
+        lib.vq_profile_next_search(None, None)
+        torch.cuda.synchronize(self.device)
+        return sum(a.elapsed_time(b) for a, b in pairs) / len(pairs)
+
     def search_statistics(self, prepared, N):
         """(vectors re-checked in fp64 -- queued for the fix-up kernel, or settled inside the filter kernel by the
         variants that do that --, (vector, codeword) pairs evaluated) of the last filter pass that used this
@@ -302,6 +318,13 @@ class HipEngine:
                                          nstate, _ptr(ws), ws.numel(), self._stream()), "vq_lbg_iterate")
             return self._mark()
 
+        distortions, conv = self._drive_stage(enqueue, state, limit)
+        return cb, distortions, conv
+
+    def _drive_stage(self, enqueue, state, limit):
+        """Enqueues iteration j + 1 before reading the record of iteration j (through the side stream), until the
+        record says the stop rule held or the iteration was gated off.  Returns (distortions, converged index or -1)."""
+        import numpy as np
         distortions, conv = [], -1
         mark = enqueue(0)
         for j in range(limit):
@@ -316,6 +339,78 @@ class HipEngine:
             if converged:
                 conv = j
                 break
+        return distortions, conv
+
+    def lbg_stage_group(self, blocks, cb, n_total, threshold, limit, group, sizes, aligned, sorted=None, shape=None,
+                        mode=None, allreduce_from_bytes=1 << 20):
+        """lbg_stage for block vectors sharded over the ranks of `group` (RCCL): per iteration this rank's
+        vq_lbg_iterate_local, one exchange on device tensors (all-gather of [sums | counts | chunk sums] while that is
+        small, else an integer all-reduce plus an all-gather of the chunk sums), vq_lbg_iterate_finish -- all enqueued
+        ahead of the host, nothing copied to the host but the 16-byte record of each iteration (side stream).  Every
+        rank computes the same records, so every rank stops at the same iteration and issues the same collectives.
+        sizes: vectors per rank; aligned: every rank but the last holding data has a multiple of 8192."""
+        import torch.distributed as dist
+        N, d = blocks.shape if blocks is not None else shape
+        cb = self._dev(cb, torch.float64).clone()
+        K = cb.shape[0]
+        if limit < 1:
+            return cb, [], -1
+        world = dist.get_world_size(group=group)
+        nstate = lib.vq_lbg_state_bytes(int(limit))
+        state = torch.empty(nstate, dtype=torch.uint8, device=self.device)
+        nacc = K * d + K
+        acc = torch.empty(nacc, dtype=torch.int64, device=self.device)
+        nch = -(-N // 8192)
+        chunk = torch.zeros(nch + 1, dtype=torch.float64, device=self.device)
+        total = torch.zeros(1, dtype=torch.float64, device=self.device)
+        width = max(1, max(-(-n // 8192) for n in sizes)) if aligned else 1
+        counts_h = (ctypes.c_int * world)(*[(-(-n // 8192) if aligned else 1) for n in sizes])
+        small = nacc * 8 * world <= allreduce_from_bytes
+        if small:
+            payload = torch.zeros(nacc + width, dtype=torch.int64, device=self.device)
+            tail = payload[nacc:].view(torch.float64)
+            gathered = torch.empty((world, nacc + width), dtype=torch.int64, device=self.device)
+            acc_total = torch.empty(nacc, dtype=torch.int64, device=self.device)
+        else:
+            payload, gathered, acc_total = None, None, acc
+            tail = torch.zeros(width, dtype=torch.float64, device=self.device)
+        chunks_all = torch.empty((world, width), dtype=torch.float64, device=self.device)
+        if self._scratch_n < N:
+            self._labels_scratch = torch.empty(N, dtype=torch.int32, device=self.device)
+            self._dist_scratch = torch.empty(N, dtype=torch.float64, device=self.device)
+            self._scratch_n = N
+        ws = self._workspace(K, d, N)
+        use_mode = self.mode if mode is None else mode
+        lab = None if (sorted is not None and use_mode == VQ_MODE_FAST and lib.vq_lbg_pass_fused(int(K), int(d))) \
+            else self._labels_scratch
+        with torch.cuda.device(self.device):
+            check(lib.vq_lbg_stage_begin(_ptr(state), nstate, int(limit), self._stream()), "vq_lbg_stage_begin")
+
+        def enqueue(j):
+            with torch.cuda.device(self.device):
+                check(lib.vq_lbg_iterate_local(_ptr(blocks), _ptr(sorted), _nbytes(sorted), N, d, _ptr(cb), K, j,
+                                               _ptr(acc[: K * d]), _ptr(acc[K * d:]), _ptr(chunk), _ptr(total), _ptr(lab),
+                                               _ptr(self._dist_scratch), use_mode, _ptr(state), nstate, _ptr(ws), ws.numel(),
+                                               self._stream()), "vq_lbg_iterate_local")
+                if aligned:
+                    if nch:
+                        tail[:nch].copy_(chunk[:nch])
+                else:
+                    tail[:1].copy_(total)
+                if small:
+                    payload[:nacc].copy_(acc)
+                    dist.all_gather_into_tensor(gathered.view(-1), payload, group=group)
+                    torch.sum(gathered[:, :nacc], dim=0, out=acc_total)     # integers: any order gives the same sums
+                    chunks_all.copy_(gathered[:, nacc:].view(torch.float64))
+                else:
+                    dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+                    dist.all_gather_into_tensor(chunks_all.view(-1), tail, group=group)
+                check(lib.vq_lbg_iterate_finish(_ptr(acc_total[: K * d]), _ptr(acc_total[K * d:]), _ptr(chunks_all), world,
+                                                width, counts_h, _ptr(cb), K, d, int(n_total), float(threshold), j,
+                                                _ptr(state), nstate, self._stream()), "vq_lbg_iterate_finish")
+            return self._mark()
+
+        distortions, conv = self._drive_stage(enqueue, state, limit)
         return cb, distortions, conv
 
     def numpy_sum(self, v):

@@ -179,11 +179,20 @@ def train_lbg(engine, blocks, k, epsilon=0.01, threshold=0.001, max_iterations=1
         done, conv_i = 0, -1
         forced = None if iters_per_stage is None else int(iters_per_stage[stage])
         limit = max_iterations if forced is None else forced
-        if group is None and hasattr(engine, "lbg_stage"):
-            # one GPU: the stage runs with the stop rule on the device, iterations enqueued ahead of the host
+        device_stage = (group is None and hasattr(engine, "lbg_stage")) or \
+                       (group is not None and hasattr(engine, "lbg_stage_group") and not _needs_host_staging(cb, group))
+        if device_stage:
+            # the stage runs with the stop rule on the device, iterations enqueued ahead of the host (several GPUs: the
+            # exchange of each iteration is enqueued between its two halves, on device tensors)
             n_d = None if blocks is not None else shape
-            cb, stage_d, conv_i = engine.lbg_stage(blocks, cb, n_total, -1.0 if forced is not None else threshold, limit,
-                                                   sorted=sorted, shape=n_d)
+            thr = -1.0 if forced is not None else threshold
+            if group is None:
+                cb, stage_d, conv_i = engine.lbg_stage(blocks, cb, n_total, thr, limit, sorted=sorted, shape=n_d)
+            else:
+                aligned, sizes = shard_info
+                cb, stage_d, conv_i = engine.lbg_stage_group(blocks, cb, n_total, thr, limit, group, sizes, aligned,
+                                                             sorted=sorted, shape=n_d,
+                                                             allreduce_from_bytes=ALLREDUCE_FROM_BYTES)
             distortions.extend(stage_d)
             done = len(stage_d)
             if conv_i >= 0:
