@@ -240,6 +240,8 @@ inline hipError_t hipDeviceGetAttribute(int *v, int attr, int) {
 }
 inline hipError_t hipFuncSetAttribute(const void *, int, int) { return hipSuccess; }
 inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+typedef void *hipEvent_t;
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 #define HIP_SYMBOL(x) (x)
 inline hipError_t hipGetSymbolAddress(void **p, const void *symbol) { *p = const_cast<void *>(symbol); return hipSuccess; }
