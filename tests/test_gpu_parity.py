@@ -803,3 +803,39 @@ def test_batch_share_of_one_gpu_encode_decode(eng, oracle):
         assert torch.equal(dec[i], eng.decode(labels[i].view(side // 4, side // 4), cb, 4, 4, 1).view(side, side))
     packed = eng.pack_labels(flat, 256)
     assert torch.equal(eng.unpack_labels(packed, flat.numel(), 256), flat)
+
+
+def test_batch_share_of_one_gpu_lbg_pass(eng, oracle):
+    """One GPU's share of the 4096-image batch (512 images of 2048^2, N = 2^27 vectors) through one LBG pass: the
+    per-column sums pass 2^32 (255 * N = 3.4e10), so the 64-bit accumulators are exercised for real.  The fused pass
+    (K = 256) and the search + separate accumulation pass (K = 1024) are both checked: counts add up to N, the column
+    totals of the cluster sums equal vq_colsum_u8, the pruned route equals the unpruned one, and sums / counts of a
+    2^20-vector slice run as its own call equal the CPU oracle's."""
+    from vector_quantization_amd import train_lbg
+    n_img, side = 512, 2048
+    batch = torch.empty((n_img, side, side), dtype=torch.uint8, device="cuda:0")
+    for i in range(0, n_img, 64):
+        batch[i: i + 64] = _structured(64 * side, side, 100 + i).view(64, side, side)
+    tall = batch.view(n_img * side, side)
+    blocks = eng.blocks_from_image(tall, 4, 4)
+    del batch, tall
+    N, d = blocks.shape
+    assert N == 1 << 27
+    col = eng.colsum(blocks)
+    assert int(col.max().item()) > 1 << 32
+    srt = eng.sort_blocks(blocks)
+    for K in (256, 1024):
+        cb = train_lbg(eng, blocks[: 1 << 18].contiguous(), K, log=None).codebook
+        acc, dist = eng.lbg_accum(None, cb, sorted=srt, shape=(N, d))             # pruned (fused at K = 256)
+        sums, counts = acc[: K * d].view(K, d), acc[K * d:]
+        assert int(counts.sum().item()) == N
+        assert torch.equal(sums.sum(dim=0), col)
+        acc_u, dist_u = eng.lbg_accum(blocks, cb)                                  # unpruned search + accumulation pass
+        assert torch.equal(acc_u, acc)
+        assert float(dist_u.item()) == float(dist.item())
+        sl = blocks[5 << 20: 6 << 20].contiguous()
+        acc_s, dist_s = eng.lbg_accum(None, cb, sorted=eng.sort_blocks(sl), shape=(1 << 20, d))
+        ref = oracle.lbg_iter(sl.cpu().numpy(), cb.cpu().numpy())
+        assert np.array_equal(acc_s[: K * d].cpu().numpy().astype(np.uint64).reshape(K, d), ref["sums"])
+        assert np.array_equal(acc_s[K * d:].cpu().numpy().astype(np.uint64), ref["counts"])
+        assert float(dist_s.item()) / (1 << 20) == ref["distortion"]

@@ -41,11 +41,16 @@ def _both(lib, check, blocks_h, cb_h, mode):
     # the static-scratch entry point: outputs only, nothing else passed in
     lab_b = torch.full((N,), -7, dtype=torch.int32, device=dev)
     dist_b = torch.full((N,), -1.0, dtype=torch.float64, device=dev)
+    # one warm-up call (module load, the look-up of the static array's address, function attributes), then the call
+    # that is checked: the device's free memory as the driver reports it (hipMemGetInfo -- it sees any hipMalloc,
+    # also one made behind torch's back) must be the same before and after
+    warm = torch.empty_like(lab_b)
+    check(lib.vq_encode_l1_static(_p(blocks), N, d, _p(cb), K, _p(warm), None, mode, stream), "vq_encode_l1_static")
     torch.cuda.synchronize(dev)
-    before = torch.cuda.memory_allocated(dev)
+    free_before = torch.cuda.mem_get_info(dev)[0]
     check(lib.vq_encode_l1_static(_p(blocks), N, d, _p(cb), K, _p(lab_b), _p(dist_b), mode, stream), "vq_encode_l1_static")
     torch.cuda.synchronize(dev)
-    assert torch.cuda.memory_allocated(dev) == before
+    assert torch.cuda.mem_get_info(dev)[0] == free_before
     return lab_a.cpu().numpy(), dist_a.cpu().numpy(), lab_b.cpu().numpy(), dist_b.cpu().numpy()
 
 
@@ -71,3 +76,33 @@ def test_static_scratch_entry_matches_workspace_entry(oracle):
     lab = torch.empty(1 << 22, dtype=torch.int32, device=dev)
     rc = lib.vq_encode_l1_static(_p(big), 1 << 22, 16, _p(cbt), cbt.shape[0], _p(lab), None, 1, None)
     assert rc == VQ_E_UNSUPPORTED and "static array holds" in last_error()
+
+
+def test_static_scratch_entry_under_stream_capture(oracle):
+    """The caller the entry point is for: a HIP graph capture, where an allocation would fail.  After one warm-up call
+    outside the capture the call is captured, the graph replayed twice, and the labels checked against the oracle."""
+    from vector_quantization_amd._lib import lib, check
+    rng = np.random.default_rng(7)
+    blocks_h, cb_h = _case(rng, 60000, 128, 16)
+    dev = torch.device("cuda:0")
+    blocks = torch.from_numpy(blocks_h).to(dev)
+    cb = torch.from_numpy(cb_h).to(dev)
+    N, d = blocks.shape
+    K = cb.shape[0]
+    lab = torch.full((N,), -7, dtype=torch.int32, device=dev)
+    dist = torch.full((N,), -1.0, dtype=torch.float64, device=dev)
+    assert lib.vq_static_scratch_bytes() == 8 << 20
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    check(lib.vq_encode_l1_static(_p(blocks), N, d, _p(cb), K, _p(lab), _p(dist), 1, stream), "warm-up")
+    torch.cuda.synchronize(dev)
+    lab.fill_(-7)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        check(lib.vq_encode_l1_static(_p(blocks), N, d, _p(cb), K, _p(lab), _p(dist), 1, st), "captured call")
+    want_l, want_d = oracle.encode_l1(blocks_h, cb_h, want_dist=True)
+    for _ in range(2):
+        lab.fill_(-7)
+        g.replay()
+        torch.cuda.synchronize(dev)
+        assert np.array_equal(lab.cpu().numpy(), want_l) and np.array_equal(dist.cpu().numpy(), want_d)
