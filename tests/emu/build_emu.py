@@ -14,7 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 SRC = os.path.join(ROOT, "vector_quantization_amd", "csrc", "vq_hip.hip")
 OUT_DIR = os.path.join(HERE, "_build")
-OUT = os.path.join(OUT_DIR, "libvqemu.so")
+# VQ_EMU_SANITIZE=1: the same build with -fsanitize=undefined (host code only), aborting on the first finding
+SANITIZE = os.environ.get("VQ_EMU_SANITIZE") == "1"
+OUT = os.path.join(OUT_DIR, "libvqemu_ubsan.so" if SANITIZE else "libvqemu.so")
 
 RUNTIME = r'''
 namespace emu {
@@ -72,12 +74,16 @@ def build(force=False):
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not force and _fresh(deps):          # another process built it while this one waited
             return OUT
-        cpp = os.path.join(OUT_DIR, "vq_hip_emu.cpp")
+        cpp = os.path.join(OUT_DIR, "vq_hip_emu_ubsan.cpp" if SANITIZE else "vq_hip_emu.cpp")
         with open(cpp, "w") as f:
             f.write(transform(open(SRC).read()))
         tmp = OUT + f".{os.getpid()}.tmp"
         cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-pthread", "-w",
                "-I", HERE, "-I", os.path.join(ROOT, "include"), cpp, "-o", tmp]
+        if SANITIZE:
+            # (alignment is left out: the kernels read rows as words only where the host has checked the alignment the
+            # GPU needs, which is weaker than what the host compiler assumes for uint4)
+            cmd[1:1] = ["-fsanitize=undefined", "-fno-sanitize=alignment", "-fno-sanitize-recover=undefined"]
         subprocess.run(cmd, check=True)
         os.replace(tmp, OUT)
     return OUT
