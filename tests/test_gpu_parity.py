@@ -645,7 +645,11 @@ def test_sort_image_golden(eng, train_case):
 @pytest.mark.parametrize("shape,bh,bw", [((7, 5, 3), 2, 2), ((33, 17, 1), 4, 4), ((64, 64, 3), 8, 8), ((9, 9, 1), 3, 3),
                                          ((130, 67, 3), 3, 5), ((16, 20, 2), 4, 2), ((515, 770, 1), 4, 4), ((300, 301, 1), 2, 2),
                                          ((398, 402, 3), 4, 4), ((37, 44, 3), 4, 4), ((3, 2, 3), 4, 4), ((1030, 516, 1), 4, 8),
-                                         ((250, 260, 3), 8, 8)])
+                                         ((250, 260, 3), 8, 8),
+                                         # rows that are not whole words: extraction + in-place sort (d <= 16, 32, 48) ...
+                                         ((200, 203, 2), 4, 4), ((333, 1001, 1), 2, 2), ((129, 255, 3), 2, 2), ((600, 601, 3), 4, 4),
+                                         # ... and the fused kernels on unaligned words (other row lengths)
+                                         ((100, 101, 3), 8, 8), ((64, 66, 1), 8, 8), ((90, 91, 3), 4, 2)])
 @pytest.mark.parametrize("pad_mode", [0, 1])
 def test_sort_image_ragged(eng, oracle, shape, bh, bw, pad_mode):
     rng = np.random.default_rng(hash((shape, bh, bw)) & 0xffff)
@@ -660,6 +664,32 @@ def test_sort_image_ragged(eng, oracle, shape, bh, bw, pad_mode):
         p = perm[w0: w0 + n].astype(np.int64)
         assert np.array_equal(np.sort(p), np.arange(n))
         assert np.array_equal(rows[w0: w0 + n], blocks[w0 + p])
+
+
+@pytest.mark.parametrize("shape,bh,bw", [((256, 256, 3), 4, 4), ((128, 260, 1), 4, 4), ((64, 64, 3), 8, 8)])
+@pytest.mark.parametrize("offset", [1, 2, 3])
+def test_image_at_an_odd_address(eng, oracle, shape, bh, bw, offset):
+    """An image that does not start on a word boundary (a view into a larger byte buffer): block extraction, the
+    image sort and labels straight from the image equal the oracle's."""
+    rng = np.random.default_rng(offset * 100 + shape[1])
+    img = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    n = img.size
+    buf = torch.zeros(n + 8, dtype=torch.uint8, device="cuda:0")
+    view = buf[offset: offset + n].view(*shape)
+    view.copy_(dev(img))
+    assert view.data_ptr() % 4 == offset
+    blocks = oracle.blocks_u8(img, bh, bw, 0)
+    N, d = blocks.shape
+    assert np.array_equal(eng.blocks_from_image(view, bh, bw).cpu().numpy(), blocks)
+    srt, nd = eng.sort_image(view, bh, bw)
+    rows, perm = _sorted_parts(srt, N, d)
+    for w0 in range(0, N, 8192):
+        m = min(8192, N - w0)
+        p = perm[w0: w0 + m].astype(np.int64)
+        assert np.array_equal(np.sort(p), np.arange(m))
+        assert np.array_equal(rows[w0: w0 + m], blocks[w0 + p])
+    cb = rng.random((64, d)) * 255.0
+    assert np.array_equal(eng.encode_image(view, bh, bw, dev(cb)).cpu().numpy(), oracle.encode_l1(blocks, cb))
 
 
 def test_encode_image_golden(eng, train_case):

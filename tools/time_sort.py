@@ -22,7 +22,8 @@ for (H, W, C, bh, bw) in [(4096, 4096, 3, 4, 4), (4096, 4096, 3, 8, 8), (8192, 8
     N, d = blocks.shape
     srt = eng.sort_blocks(blocks)
     srt2, _ = eng.sort_image(img, bh, bw)
+    t_x = timeit(lambda: eng.blocks_from_image(img, bh, bw))
     t_b = timeit(lambda: eng.sort_blocks(blocks, out=srt))
     t_i = timeit(lambda: eng.sort_image(img, bh, bw, out=srt2))
     gb = N * (2 * d + 2) / 1e9
-    print(f"H={H} W={W} C={C} {bh}x{bw} N={N} d={d}: sort_blocks {t_b:7.1f} us ({gb / t_b * 1e6:6.0f} GB/s)  sort_image {t_i:7.1f} us ({gb / t_i * 1e6:6.0f} GB/s)")
+    print(f"H={H} W={W} C={C} {bh}x{bw} N={N} d={d}: extract {t_x:6.1f} us  sort_blocks {t_b:7.1f} us ({gb / t_b * 1e6:6.0f} GB/s)  sort_image {t_i:7.1f} us ({gb / t_i * 1e6:6.0f} GB/s)")

@@ -298,6 +298,16 @@ inline void sload_x2(u32x2 &r, const uint32_t *base, uint32_t byte_off) {
 inline void sload_wait(u32x16 &, u32x2 &) {}
 #endif  // VQ_HOST_EMULATION
 
+// Four bytes at ANY byte address as one word.  Global memory takes unaligned accesses on this hardware (one load
+// instruction, served at a fraction of the aligned rate; assembling the word from its two aligned neighbours with a
+// funnel shift was measured slower still), which is what lets images whose rows are not whole words (W * C % 4 != 0:
+// most RGB photographs) be read word-wise like all others.
+__device__ __forceinline__ uint32_t load_u32_any(const uint8_t *p) {
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
 // fp64 -> uint8 the way numpy converts inside np.array(..., dtype=np.uint8): truncate toward
 // zero and keep the low 8 bits; magnitudes beyond the int32 range (and NaN) give 0.
 __device__ __forceinline__ uint8_t cast_u8(double v) {
@@ -383,8 +393,8 @@ __device__ __forceinline__ void exact_search_wave(uint32_t xv0, const uint8_t *_
 // ------------------------------------------------------------------------------------------------
 // One thread per group of G consecutive bytes of the block matrix.  G = 16 (four 4-byte words,
 // one 16-byte store) or 4 when a block row segment (bw*C bytes) is a multiple of 4, else 1.  A
-// word that lies inside the image and is 4-byte aligned there is fetched with one load; words in
-// the padding (or in an image whose rows are not word-aligned) are assembled byte by byte.
+// word that lies inside the image is fetched with one load (at whatever byte alignment the image row gives
+// it); words in the padding are assembled byte by byte.
 template <int G>
 __global__ __launch_bounds__(256) void k_blocks_u8(const uint8_t *__restrict__ img, int H, int W, int C, int bh,
                                                    int bw, int pad_zero, uint8_t *__restrict__ blocks, int nc,
@@ -423,7 +433,7 @@ __global__ __launch_bounds__(256) void k_blocks_u8(const uint8_t *__restrict__ i
                 int64_t xb = (int64_t)q * seg + rem;           // byte offset inside the (padded) image row
                 uint32_t v;
                 if (img_words_ok && xb + 4 <= rowbytes && (y < H || !pad_zero)) {
-                    v = *reinterpret_cast<const uint32_t *>(img + (size_t)yc * rowbytes + xb);
+                    v = load_u32_any(img + (size_t)yc * rowbytes + xb);
                 } else {
                     v = 0;
 #pragma unroll
@@ -1052,7 +1062,7 @@ struct SrcImage {
     const uint8_t *img;
     int H, W, C, bh, bw, pad_zero;
     uint32_t nc, seg, d;          // blocks per block row, bytes per block row segment (bw * C), bh * seg
-    int words_ok;                 // image rows are whole aligned words (W * C % 4 == 0, base aligned)
+    int words_ok;                 // words inside the image may be read with one load (at any byte alignment: load_u32_any)
     int quads_ok;                 // 4x4 blocks of 1-byte pixels, no padding, image rows multiples of 16 aligned bytes
     int fast32;                   // every byte offset into the image fits 32 bits
     // direct addressing: blocks that need no padding are read at origin() + vec_base + word_off
@@ -1100,7 +1110,7 @@ struct SrcImage {
         const int64_t rowbytes = (int64_t)W * C;
         const int64_t xb = (int64_t)q * seg + rem;           // byte offset inside the (padded) image row
         if (words_ok && (seg & 3u) == 0 && xb + 4 <= rowbytes && (y < H || !pad_zero))
-            return *reinterpret_cast<const uint32_t *>(img + (size_t)yc * rowbytes + xb);
+            return load_u32_any(img + (size_t)yc * rowbytes + xb);
         uint32_t v = 0;
 #pragma unroll
         for (int t = 0; t < 4; ++t) v |= byte_at(r, q, e + t) << (8 * t);
@@ -1203,7 +1213,7 @@ __global__ __launch_bounds__(1024) void k_window_sort(const SRC src, int64_t N, 
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
                 const uint32_t at = base[j] != 0xffffffffu ? base[j] + off : 0u;
-                sum[j] = __builtin_amdgcn_sad_u8(*reinterpret_cast<const uint32_t *>(org + at), 0u, sum[j]);
+                sum[j] = __builtin_amdgcn_sad_u8(load_u32_any(org + at), 0u, sum[j]);
             }
         }
 #pragma unroll
@@ -1290,7 +1300,7 @@ __global__ __launch_bounds__(1024) void k_window_sort(const SRC src, int64_t N, 
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const uint32_t at = base[u] != 0xffffffffu ? base[u] + s_woff[ww[u]] : 0u;
-                    val[u] = *reinterpret_cast<const uint32_t *>(org + at);
+                    val[u] = load_u32_any(org + at);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u)
@@ -1344,7 +1354,7 @@ __global__ __launch_bounds__(1024) void k_sort_sums(const SRC src, int64_t N, in
             if (inside) {
 #pragma unroll 8
                 for (int w = 0; w < dw; ++w)
-                    sum = __builtin_amdgcn_sad_u8(*reinterpret_cast<const uint32_t *>(org + (uint32_t)(base + s_woff[w])), 0u, sum);
+                    sum = __builtin_amdgcn_sad_u8(load_u32_any(org + (uint32_t)(base + s_woff[w])), 0u, sum);
             } else {
                 for (int w = 0; w < dw; ++w) sum = __builtin_amdgcn_sad_u8(src.word(w0 + li, w), 0u, sum);
             }
@@ -1410,7 +1420,7 @@ __global__ __launch_bounds__(1024) void k_sort_gather(const SRC src, int64_t N, 
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const uint32_t at = base[u] != 0xffffffffu ? base[u] + s_woff[ww[u]] : 0u;
-                    val[u] = *reinterpret_cast<const uint32_t *>(org + at);
+                    val[u] = load_u32_any(org + at);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u)
@@ -1630,7 +1640,7 @@ __global__ __launch_bounds__(512) void k_window_sort_regs(const SRC src, int64_t
                 const uint32_t off = s_woff[w];
 #pragma unroll
                 for (int jj = 0; jj < GRP; ++jj)
-                    keep[h * GRP + jj][w] = *reinterpret_cast<const uint32_t *>(org + (uint32_t)(base[jj] + off));
+                    keep[h * GRP + jj][w] = load_u32_any(org + (uint32_t)(base[jj] + off));
             }
         }
     } else {
@@ -4159,7 +4169,8 @@ bool sort_in_registers_ok(const SrcImage &s) {
 // Fills `sorted` (rows, origins, header) from a vector source.  row_words_ok: rows are whole words the
 // source can deliver aligned; rows of one to four such words are staged in LDS and leave in order.
 template <class SRC>
-int run_sort(const SRC &src, bool row_words_ok, int64_t N, int d, void *sorted, size_t sorted_bytes, hipStream_t st) {
+int run_sort(const SRC &src, bool row_words_ok, int64_t N, int d, void *sorted, size_t sorted_bytes, hipStream_t st,
+             bool in_place = false) {
     const bool words = row_words_ok && d <= 16;
     if (d > MAX_D_FAST) return fail(VQ_E_UNSUPPORTED, "d=%d is beyond the fast kernels", d);
     if (N > 0xfffffff0LL) return fail(VQ_E_UNSUPPORTED, "N=%lld exceeds 2^32 per call", (long long)N);
@@ -4210,6 +4221,8 @@ int run_sort(const SRC &src, bool row_words_ok, int64_t N, int d, void *sorted, 
         else VQ_LAUNCH_SORT_REGS(8);
 #undef VQ_LAUNCH_SORT_REGS
     } else {
+        // (the two kernels above have read a window completely before they write it; this one has not)
+        if (in_place) return fail(VQ_E_HIP, "internal: the generic window sort cannot run in place");
         // few windows: the rows are copied by a second launch with several workgroups per window
         int parts = 1;
         if (grid * 4 <= di.cus) parts = di.cus / grid < 16 ? di.cus / grid : 16;   // (two parts per window: measured no gain)
@@ -4276,7 +4289,7 @@ int vq_blocks_u8(const uint8_t *img, int H, int W, int C, int bh, int bw, int pa
     int64_t d = (int64_t)bh * bw * C;
     int64_t total = (int64_t)nr * nc * d;
     const uintptr_t optr = reinterpret_cast<uintptr_t>(blocks);
-    const int words_ok = (((int64_t)W * C) % 4 == 0) && ((reinterpret_cast<uintptr_t>(img) & 3) == 0);
+    const int words_ok = 1;                                 // (unaligned word loads: see load_u32_any)
     const bool seg4 = (bw * C) % 4 == 0;
     const int pz = pad_mode == VQ_PAD_ZERO;
     if (C == 1 && bh == 4 && bw == 4 && H % 4 == 0 && W % 16 == 0 && (optr & 15) == 0 &&
@@ -4419,10 +4432,27 @@ int vq_blocks_sort_img(const uint8_t *img, int H, int W, int C, int bh, int bw, 
     SrcImage src;
     src.img = img; src.H = H; src.W = W; src.C = C; src.bh = bh; src.bw = bw; src.pad_zero = pad_mode == VQ_PAD_ZERO;
     src.nc = (uint32_t)nc; src.seg = (uint32_t)(bw * C); src.d = (uint32_t)d;
-    src.words_ok = (((int64_t)W * C) % 4 == 0) && ((reinterpret_cast<uintptr_t>(img) & 3) == 0);
+    src.words_ok = 1;                                       // (unaligned word loads: see load_u32_any)
     src.quads_ok = C == 1 && bh == 4 && bw == 4 && H % 4 == 0 && W % 16 == 0 && (reinterpret_cast<uintptr_t>(img) & 15) == 0;
     src.fast32 = (unsigned long long)H * (unsigned long long)W * (unsigned long long)C < (1ull << 32) ? 1 : 0;
-    return run_sort(src, d % 4 == 0, nr * nc, d, sorted, sorted_bytes, static_cast<hipStream_t>(stream));
+    // Images whose rows are not whole aligned words (W * C % 4 != 0: most RGB photographs) are read with unaligned
+    // loads, which the fused kernels pay for dearly (4090 x 4090 RGB, 4x4 blocks: 128 us against 34 us for 4096 x 4096).
+    // Where the block-matrix sort can run in place -- rows of up to 16, 32 or 48 bytes: a window is read completely
+    // before it is written -- such an image is extracted into the rows region of `sorted` (a streaming pass that
+    // takes the unaligned loads in its stride) and sorted there: 68 us for the same image.
+    const bool unaligned = ((int64_t)W * C) % 4 != 0 || (reinterpret_cast<uintptr_t>(img) & 3) != 0;
+    const int64_t N = nr * nc;
+    if (unaligned && d % 4 == 0 && (d <= 16 || d == 32 || d == 48) && N > 0) {
+        const SortedLayout SL = sorted_layout(d, N);
+        if (!sorted) return fail(VQ_E_INVALID, "null pointer");
+        if (sorted_bytes < SL.total) return fail(VQ_E_WORKSPACE, "sorted buffer of %zu bytes needed, %zu given", SL.total, sorted_bytes);
+        if (reinterpret_cast<uintptr_t>(sorted) & 15) return fail(VQ_E_INVALID, "sorted buffer must be 16-byte aligned");
+        uint8_t *rows = reinterpret_cast<uint8_t *>(static_cast<char *>(sorted) + SL.rows);
+        int rc = vq_blocks_u8(img, H, W, C, bh, bw, pad_mode, rows, stream);
+        if (rc) return rc;
+        return run_sort(SrcBlocks{rows, d}, true, N, d, sorted, sorted_bytes, static_cast<hipStream_t>(stream), true);
+    }
+    return run_sort(src, d % 4 == 0, N, d, sorted, sorted_bytes, static_cast<hipStream_t>(stream));
 }
 
 int vq_encode_l1_img(const uint8_t *img, int H, int W, int C, int bh, int bw, int pad_mode, const double *cb, int K,
