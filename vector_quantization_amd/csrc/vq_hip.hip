@@ -838,12 +838,12 @@ __global__ __launch_bounds__(1024) void k_prep_finish(int K, int d, int dp2, uin
 // adjacent threads per codeword: each holds 16 / TPC entries in registers from the single read of the
 // codebook to the writes at the sorted place, partial sums are combined across the TPC lanes, and the ranking
 // scan is split between them.  Global stores come last, so that nothing waits for them.
+// (A device function: k_prepare_small runs it on its own, k_lbg_finish_t behind the centroid update of an LBG
+// iteration, for the next one.  s_keys: the workgroup's dynamic LDS.)
 template <int TPC>
-__global__ __launch_bounds__(1024) void k_prepare_small(const double *__restrict__ cb, int K, int d, int dp2,
-                                                        uint32_t clim, PrepHeader *__restrict__ hdr,
-                                                        uint32_t *__restrict__ c16, uint32_t *__restrict__ bias,
-                                                        double *__restrict__ cbT, uint32_t *__restrict__ postab) {
-    extern __shared__ __align__(16) unsigned long long s_keys[];
+__device__ __forceinline__ void prepare_small_body(const double *cb, int K, int d, int dp2, uint32_t clim, PrepHeader *hdr,
+                                                   uint32_t *c16, uint32_t *bias, double *cbT, uint32_t *postab,
+                                                   unsigned long long *s_keys) {
     __shared__ uint32_t s_cmax;
     __shared__ uint32_t s_emax;
     __shared__ __align__(16) uint32_t s_sc[1024 + 4];            // element sum of each fixed-point row, original order
@@ -1013,6 +1013,15 @@ __global__ __launch_bounds__(1024) void k_prepare_small(const double *__restrict
         hdr->tshift = tshift;
         hdr->nt = nt;
     }
+}
+
+template <int TPC>
+__global__ __launch_bounds__(1024) void k_prepare_small(const double *__restrict__ cb, int K, int d, int dp2,
+                                                        uint32_t clim, PrepHeader *__restrict__ hdr,
+                                                        uint32_t *__restrict__ c16, uint32_t *__restrict__ bias,
+                                                        double *__restrict__ cbT, uint32_t *__restrict__ postab) {
+    extern __shared__ __align__(16) unsigned long long s_keys[];
+    prepare_small_body<TPC>(cb, K, d, dp2, clim, hdr, c16, bias, cbT, postab, s_keys);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3168,7 +3177,7 @@ __global__ __launch_bounds__(1024) void k_npsum_final(const double *__restrict__
 // The tail of an LBG iteration in two launches (everything of VQ_Full.py:81-98 that follows the assignment when
 // the search accumulated into the replica tables).  k_lbg_fold: every workgroup folds its share of the replica
 // tables into sums / counts -- leaving the replicas zeroed for the next iteration -- and sums its 8192-element
-// chunks of the winning distances.  k_lbg_finish (one workgroup): the chunk sums in numpy's order, the centroid
+// chunks of the winning distances.  k_lbg_finish_t (one workgroup): the chunk sums in numpy's order, the centroid
 // update in place and the stop rule.
 // perm non-null: the distances of the full chunks lie in the order of the window-sorted vectors (a chunk is a sort
 // window); the workgroup puts a chunk back into the caller's order in LDS (64 KB) and sums it from there.
@@ -3228,11 +3237,23 @@ __global__ __launch_bounds__(512) void k_lbg_fold(const double *__restrict__ min
     }
 }
 
-__global__ __launch_bounds__(1024) void k_lbg_finish(const double *__restrict__ min_dist, int64_t N, int64_t nfull,
-                                                     double *__restrict__ chunk_sums,
-                                                     const unsigned long long *__restrict__ sums,
-                                                     const unsigned long long *__restrict__ counts, double *cb, int K,
-                                                     int d, double n_total, double threshold, LbgState *state, Gate g) {
+// TPC > 0: the same workgroup then prepares the workspace for the updated codebook (prepare_small_body), which the
+// next iteration of the stage would otherwise do in a launch of its own.
+struct PrepArgs {
+    int dp2;
+    uint32_t clim;
+    PrepHeader *hdr;
+    uint32_t *c16, *bias, *postab;
+    double *cbT;
+};
+template <int TPC>
+__global__ __launch_bounds__(1024) void k_lbg_finish_t(const double *__restrict__ min_dist, int64_t N, int64_t nfull,
+                                                       double *__restrict__ chunk_sums,
+                                                       const unsigned long long *__restrict__ sums,
+                                                       const unsigned long long *__restrict__ counts, double *cb, int K,
+                                                       int d, double n_total, double threshold, LbgState *state, Gate g,
+                                                       const PrepArgs pa) {
+    extern __shared__ __align__(16) unsigned long long s_prepkeys[];
     if (gate_closed(g)) return;
     const double total = npsum_final_block<1024>(min_dist, N, nfull, chunk_sums);
     for (int i = threadIdx.x; i < K * d; i += 1024) {
@@ -3242,6 +3263,10 @@ __global__ __launch_bounds__(1024) void k_lbg_finish(const double *__restrict__ 
     if (threadIdx.x == 0) {
         state->dist_sum = total;
         apply_stop_rule(state, total, n_total, threshold, g.iter);
+    }
+    if constexpr (TPC > 0) {
+        __syncthreads();                                       // the updated codebook is visible to the whole workgroup
+        prepare_small_body<TPC>(cb, K, d, pa.dp2, pa.clim, pa.hdr, pa.c16, pa.bias, pa.cbT, pa.postab, s_prepkeys);
     }
 }
 
@@ -3797,11 +3822,12 @@ struct TailLeft {
     const void *state;
     int iteration, K, d;
     int64_t N;
+    bool prepared;                   // the workspace is already prepared for the codebook that call left behind
 };
-thread_local TailLeft g_tail_left = {nullptr, nullptr, 0, 0, 0, 0};
+thread_local TailLeft g_tail_left = {nullptr, nullptr, 0, 0, 0, 0, false};
 
 int check_ws(const void *ws, size_t ws_bytes, int K, int d, int64_t N) {
-    g_tail_left = TailLeft{nullptr, nullptr, 0, 0, 0, 0};
+    g_tail_left = TailLeft{nullptr, nullptr, 0, 0, 0, 0, false};
     size_t need = ws_layout(K, d, N).total;
     if (!ws || ws_bytes < need) return fail(VQ_E_WORKSPACE, "workspace of %zu bytes needed, %zu given", need, ws_bytes);
     return VQ_OK;
@@ -4630,9 +4656,10 @@ int lbg_iterate_impl(const uint8_t *blocks, const void *sorted, size_t sorted_by
     // what the previous call on this thread left behind is read before check_ws forgets it
     const bool chained = g_tail_left.ws == ws && g_tail_left.state == state && g_tail_left.iteration + 1 == iteration &&
                          g_tail_left.K == K && g_tail_left.d == d && g_tail_left.N == N;
+    const bool prepared = chained && g_tail_left.prepared;
     int rc = check_ws(ws, ws_bytes, K, d, N);
     if (rc) return rc;
-    // The fused form: the search accumulates into the replica tables, k_lbg_fold and k_lbg_finish do the rest.
+    // The fused form: the search accumulates into the replica tables, k_lbg_fold and k_lbg_finish_t do the rest.
     // The fold leaves the replica tables zeroed, so only the first iteration of a run of consecutive calls made by
     // one host thread (same workspace, same state, same N, iteration numbers counting up, no other call on the
     // workspace in between) zeroes them.
@@ -4652,8 +4679,10 @@ int lbg_iterate_impl(const uint8_t *blocks, const void *sorted, size_t sorted_by
             HIP_TRY(hipMemsetAsync(w + LN.qcount, 0, (size_t)NQ * 64, st));
         }
         g_ws_zeroed = true;
-        rc = run_prepare(cb, K, d, ws, st);
-        if (rc) return rc;
+        if (!prepared) {                                       // (else the previous iteration's last kernel has done it)
+            rc = run_prepare(cb, K, d, ws, st);
+            if (rc) return rc;
+        }
         // the winning distances of whole chunks are stored in the order of the sorted vectors (full-width stores) and
         // put back into the caller's order by the fold kernel, in LDS; labels are written only when asked for
         rc = run_fast(blocks, sorted, sorted_bytes, N, d, cb, K, labels, min_dist, reinterpret_cast<unsigned long long *>(sums),
@@ -4673,16 +4702,35 @@ int lbg_iterate_impl(const uint8_t *blocks, const void *sorted, size_t sorted_by
         hipLaunchKernelGGL(k_lbg_fold, dim3((unsigned)grid), dim3(512), fold_lds, st, min_dist, perm, nfull, chunk_sums,
                            reinterpret_cast<unsigned long long *>(w + L0.acc_rep), K, d, s64, c64, g_gate);
         LAUNCH_CHECK("k_lbg_fold");
+        bool prep_next = false;
         if (finish) {
-            hipLaunchKernelGGL(k_lbg_finish, dim3(1), dim3(1024), 0, st, min_dist, N, nfull, chunk_sums, s64, c64, cb, K, d,
-                               (double)n_total, threshold, S, g_gate);
+            // shapes of the one-workgroup prepare kernel: its work for the NEXT iteration rides on this launch
+            prep_next = d <= 16 && K <= 512;
+            PrepArgs pa;
+            pa.dp2 = dp2_bucket(d);
+            pa.clim = key_layout(K, pa.dp2).clim;
+            pa.hdr = reinterpret_cast<PrepHeader *>(w + L0.header);
+            pa.c16 = reinterpret_cast<uint32_t *>(w + L0.c16);
+            pa.bias = reinterpret_cast<uint32_t *>(w + L0.bias);
+            pa.postab = reinterpret_cast<uint32_t *>(w + L0.postab);
+            pa.cbT = reinterpret_cast<double *>(w + L0.cbT);
+            const size_t hash_lds = (K <= PREP_HASH_CAP && K > 1) ? (size_t)K * 32 : 16;
+            if (!prep_next)
+                hipLaunchKernelGGL(k_lbg_finish_t<0>, dim3(1), dim3(1024), 0, st, min_dist, N, nfull, chunk_sums, s64, c64, cb,
+                                   K, d, (double)n_total, threshold, S, g_gate, pa);
+            else if (K <= 256)
+                hipLaunchKernelGGL(k_lbg_finish_t<4>, dim3(1), dim3(1024), hash_lds, st, min_dist, N, nfull, chunk_sums, s64,
+                                   c64, cb, K, d, (double)n_total, threshold, S, g_gate, pa);
+            else
+                hipLaunchKernelGGL(k_lbg_finish_t<2>, dim3(1), dim3(1024), hash_lds, st, min_dist, N, nfull, chunk_sums, s64,
+                                   c64, cb, K, d, (double)n_total, threshold, S, g_gate, pa);
             LAUNCH_CHECK("k_lbg_finish");
         } else {
             // the trailing partial chunk and the total of this call's chunk sums
             hipLaunchKernelGGL(k_npsum_final, dim3(1), dim3(1024), 0, st, min_dist, N, nfull, chunk_sums, total_out);
             LAUNCH_CHECK("k_npsum_final");
         }
-        g_tail_left = TailLeft{ws, state, iteration, K, d, N};
+        g_tail_left = TailLeft{ws, state, iteration, K, d, N, prep_next};
         return VQ_OK;
     }
     // one launch zeroes the caller's sums and counts, the queue counters and the replica tables of the workspace
