@@ -1807,6 +1807,7 @@ struct AssignArgs {
     int64_t dist_sorted_end;    // PRUNE: the distances of the vectors at sorted positions below this go to min_dist at
                                 // their SORTED position (coalesced stores; the reader un-permutes), the others by origin
     int cb_lds;                 // ACC: 1 = the fp64 codebook is staged in LDS (rows of d + 1 doubles) for the winners' distances
+    int persist_tiles;          // ACC: > 0 = resident workgroups; every XCD's waves share this many tiles of 64 * R vectors
     int heavy_first;            // PRUNE: 1 = tiles from the middle of the sort windows are dispatched first (few-round launches)
     Gate gate;
 };
@@ -1922,15 +1923,15 @@ __global__ __launch_bounds__(ACC ? 1024 : 512) VQ_ASSIGN_ATTR void k_assign_fast
     }
     // One tile per workgroup (the host launches at least ntiles workgroups): nothing is carried from tile to tile, so
     // no value has to stay live across the whole kernel.
-    if (const int64_t tile = first_tile; tile < a.ntiles) {
-        const int64_t base = tile * (int64_t)(BLOCK * R);
+    // (base: the first vector of the tile; wave_off: where in it this wave's 64 * R vectors start)
+    auto do_tile = [&](const int64_t base, const int wave_off) {
         // ---- load R vectors per lane and convert to packed 16-bit fixed point ----
         uint32_t x[R][DP2];
         uint32_t origin[R];                                    // PRUNE: where in its window the vector came from
         // position of lane's r-th vector: a wave takes 64 * R consecutive vectors when pruning (they are
         // neighbours in sorted order), otherwise the R vectors of a lane are a workgroup apart
         auto vec_index = [&](int r) -> int64_t {
-            return PRUNE ? base + (int64_t)(tid >> 6) * (WAVE * R) + r * WAVE + lane : base + (int64_t)r * BLOCK + tid;
+            return PRUNE ? base + wave_off + r * WAVE + lane : base + (int64_t)r * BLOCK + tid;
         };
         // The vectors are requested first and looked at last: the header reads below (three more memory round trips)
         // run while they are on their way.  Word-wise rows wait in x[r][even] as they came.
@@ -1972,8 +1973,8 @@ __global__ __launch_bounds__(ACC ? 1024 : 512) VQ_ASSIGN_ATTR void k_assign_fast
             // is written
             if (a.shdr->magic != SORTED_MAGIC || a.shdr->N != (unsigned long long)a.N || a.shdr->d != (uint32_t)a.d) {
                 for (int r = 0; r < R; ++r) {
-                    const int64_t n = base + (int64_t)r * BLOCK + tid;
-                    if (n < a.N) a.labels[n] = -1;
+                    const int64_t n = vec_index(r);
+                    if (n < a.N && a.labels) a.labels[n] = -1;
                 }
                 return;
             }
@@ -2505,7 +2506,29 @@ __global__ __launch_bounds__(ACC ? 1024 : 512) VQ_ASSIGN_ATTR void k_assign_fast
                 a.min_dist[PRUNE && ns < a.dist_sorted_end ? ns : n] = acc;
             }
         }
+    };
+    bool looped = false;
+    if constexpr (ACC) {
+        if (a.persist_tiles > 0) {
+            // Resident workgroups whose waves fetch tiles of 64 * R vectors until their XCD's share is used up: the LDS
+            // table and the LDS copy of the codebook are set up and flushed once per workgroup instead of once per
+            // tile, and a wave that is done with a tile does not wait for the rest of its workgroup.  The counters
+            // (word 4 of the first eight counter slots) are zeroed with the queue counters before the launch.
+            looped = true;
+            const uint32_t xcd = blockIdx.x & 7;
+            uint32_t *ctr = a.qcount + 16 * xcd + 4;
+            for (;;) {
+                uint32_t t = 0;
+                if (lane == 0) t = atomicAdd(ctr, 1u);
+                t = __builtin_amdgcn_readfirstlane(t);
+                if (t >= (uint32_t)a.persist_tiles) break;
+                const int64_t wbase = ((int64_t)xcd * a.persist_tiles + t) * (WAVE * R);
+                if (wbase >= a.N) break;
+                do_tile(wbase, 0);
+            }
+        }
     }
+    if (!looped && first_tile < a.ntiles) do_tile(first_tile * (int64_t)(BLOCK * R), (tid >> 6) * (WAVE * R));
 #ifdef VQ_TIMELINE
     {
         const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (tid >> 6);
@@ -3213,12 +3236,14 @@ __global__ __launch_bounds__(512) void k_lbg_fold(const double *__restrict__ min
                                                   int64_t nfull,
                                                   double *__restrict__ chunk_sums, unsigned long long *__restrict__ rep,
                                                   int K, int d, unsigned long long *__restrict__ sums,
-                                                  unsigned long long *__restrict__ counts, Gate g) {
+                                                  unsigned long long *__restrict__ counts, uint32_t *__restrict__ qcount,
+                                                  Gate g) {
     extern __shared__ __align__(16) double s_dist[];            // perm non-null: one chunk of distances
     __shared__ double s_leaf[64];
     if (gate_closed(g)) return;
     const int tid = threadIdx.x;
     const int tabn = K * (d + 1);
+    if (blockIdx.x == 0 && tid < 8) qcount[16 * tid + 4] = 0u;   // the tile counters of the resident search workgroups
     for (int i = blockIdx.x * 512 + tid; i < tabn; i += gridDim.x * 512) {
         unsigned long long t = 0;
 #pragma unroll 8
@@ -4039,6 +4064,16 @@ int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int
     a.rows = nullptr; a.perm = nullptr; a.shdr = nullptr;
     a.dist_sorted_end = (prune && dist_sorted) ? N / NP_CHUNK * NP_CHUNK : 0;
     a.cb_lds = acc_cb_lds ? 1 : 0;
+    a.persist_tiles = 0;
+#ifndef VQ_NO_PERSIST
+    if (acc_cb_lds && ntiles >= (int64_t)4 * di.cus) {         // (several rounds of workgroups: two resident ones per compute unit)
+        const int64_t wave_tiles = (N + (int64_t)WAVE * R - 1) / ((int64_t)WAVE * R);
+        // an XCD's share in whole sort windows, so that the tiles of a window stay on one XCD
+        const int64_t per_win = SORT_WIN / (WAVE * R);
+        a.persist_tiles = (int)(((wave_tiles + 7) / 8 + per_win - 1) / per_win * per_win);
+        grid = 2 * di.cus;
+    }
+#endif
     a.heavy_first = (prune && grid <= 16 * di.cus) ? (grid <= 4 * di.cus ? 2 : 1) : 0;
     a.gate = g_gate;
     a.postab = reinterpret_cast<const uint32_t *>(w + L.postab);
@@ -4700,7 +4735,8 @@ int lbg_iterate_impl(const uint8_t *blocks, const void *sorted, size_t sorted_by
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lbg_fold), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)fold_lds));
         hipLaunchKernelGGL(k_lbg_fold, dim3((unsigned)grid), dim3(512), fold_lds, st, min_dist, perm, nfull, chunk_sums,
-                           reinterpret_cast<unsigned long long *>(w + L0.acc_rep), K, d, s64, c64, g_gate);
+                           reinterpret_cast<unsigned long long *>(w + L0.acc_rep), K, d, s64, c64,
+                           reinterpret_cast<uint32_t *>(w + LN.qcount), g_gate);
         LAUNCH_CHECK("k_lbg_fold");
         bool prep_next = false;
         if (finish) {
