@@ -16,3 +16,4 @@ timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpur
 echo "trace done"
 bash tools/gpu_pmc.sh || exit 1
 echo "pmc done"
+bash tools/gpu_pmc_shapes.sh || exit 1

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Copies the rocprofv3 outputs of tools/gpu_round.sh from gpurun_out/ into profiles/ (filtered to this
 library's kernels) and derives the per-kernel PMC table and the summary bench.py reads.
-Usage: python3 tools/make_profiles.py r02"""
+Usage: python3 tools/make_profiles.py r03"""
 import collections
 import csv
 import glob
@@ -12,7 +12,7 @@ import shutil
 import statistics
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 src = os.path.join(root, "gpurun_out")
@@ -115,9 +115,56 @@ summary = dict(
     hbm_bytes_by_kernel={e["kernel"]: e["hbm_read_bytes"] + e["hbm_write_bytes"] for e in big
                          if full_size(e["kernel"])},
     valu={e["kernel"]: dict(valu_wave_insts=e["counters"]["SQ_INSTS_VALU"], valu_issue_busy_frac=e["valu_issue_busy_frac"])
-          for e in per_kernel if "valu_issue_busy_frac" in e and e["kernel"].startswith("k_assign_fast") and grid_of(e["kernel"]) >= 1048576},
+          for e in per_kernel if "valu_issue_busy_frac" in e and e["kernel"].startswith("k_assign_fast") and grid_of(e["kernel"]) >= 262144},
     note="FETCH_SIZE (KB) doubled per the gfx950 correction for wide coalesced reads; WRITE_SIZE (KB) as is; separate "
          "rocprofv3 --pmc passes over tools/prof_encode.py on the library build named above (PMC passes run at lower "
          "clocks than un-profiled runs: durations come from the kernel trace, not from these passes).")
 json.dump(summary, open(os.path.join(out, f"{tag}_pmc_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
+
+# ---- PMC passes over tools/prof_shapes.py (d = 192 / K = 4096, d = 48 / K = 256, K = 1024 / d = 16) ------------------
+# kept: the launches over the measured images (large grids) of the search, fix-up, sort and accumulation kernels
+KEEP = ("k_assign_fast", "k_fixup", "k_window_sort", "k_sort_", "k_accum_dist", "k_prep_")
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+shape_dir = os.path.join(src, "pmc_shapes")
+for name in ("sq1", "sq2", "lds", "fetch", "write"):
+    files = glob.glob(os.path.join(shape_dir, name, "**", "p_counter_collection.csv"), recursive=True)
+    if not files:
+        continue
+    rows = [r for r in csv.DictReader(open(files[0]))
+            if short(r["Kernel_Name"]).startswith(KEEP) and int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0) >= 65536]
+    if not rows:
+        continue
+    with open(os.path.join(out, f"{tag}_pmc_shapes_{name}.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(rows)
+    for r in rows:
+        key = f"{short(r['Kernel_Name'])}[grid={r.get('Grid_Size', r.get('Grid_Size_X', ''))}]"
+        agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+shapes = []
+for key in sorted(agg):
+    c = {n: sum(v) / len(v) for n, v in agg[key].items()}
+    e = dict(kernel=key, dispatches=max(len(v) for v in agg[key].values()), counters=c)
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        e["hbm_read_bytes"] = c["FETCH_SIZE"] * 1024 * 2
+        e["hbm_write_bytes"] = c["WRITE_SIZE"] * 1024
+    if "GRBM_GUI_ACTIVE" in c and "SQ_INSTS_VALU" in c:
+        e["shader_cycles"] = c["GRBM_GUI_ACTIVE"] / 8
+        e["valu_issue_busy_frac"] = c["SQ_INSTS_VALU"] * 4 / (e["shader_cycles"] * 1024)
+    if "SQ_WAVE_CYCLES" in c and "SQ_WAVES" in c and "GRBM_GUI_ACTIVE" in c:
+        # SQ_WAVE_CYCLES counts quad-cycles: mean resident waves per SIMD over the launch
+        e["mean_waves_per_simd"] = c["SQ_WAVE_CYCLES"] * 4 / (c["GRBM_GUI_ACTIVE"] / 8 * 1024)
+    if "SQ_LDS_IDX_ACTIVE" in c and "GRBM_GUI_ACTIVE" in c:
+        e["lds_active_frac_per_cu"] = c["SQ_LDS_IDX_ACTIVE"] / 256 / (c["GRBM_GUI_ACTIVE"] / 8)
+    shapes.append(e)
+if shapes:
+    json.dump(dict(library_sha256_16=lib_sha, workload="tools/prof_shapes.py", kernels=shapes),
+              open(os.path.join(out, f"{tag}_pmc_shapes_per_kernel.json"), "w"), indent=1)
+    trace = glob.glob(os.path.join(shape_dir, "trace", "**", "p_kernel_stats.csv"), recursive=True)
+    if trace:
+        rows = [r for r in csv.DictReader(open(trace[0])) if is_ours(r["Name"])]
+        with open(os.path.join(out, f"{tag}_shapes_kernel_stats.csv"), "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+            w.writeheader()
+            w.writerows(rows)

@@ -8,7 +8,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import structured_image  # noqa: E402
-from vector_quantization_amd import HipEngine, train_lbg, lbg_iteration  # noqa: E402
+from vector_quantization_amd import HipEngine, train_lbg  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 dev = torch.device("cuda:0")
@@ -27,9 +27,7 @@ for _ in range(reps):
 for _ in range(reps):
     eng.encode_image(img, 4, 4, cb, scratch=srt, labels=labels)          # image sort + prepare + pruned search + fix-up
     eng.decode(labels.view(2048, 2048), cb, 4, 4, 1)
-cur = cb
-for _ in range(reps):
-    cur, _ = lbg_iteration(eng, blocks, cur, N, sorted=srt)              # fused LBG iteration
+eng.lbg_stage(None, cb, N, -1.0, reps, sorted=srt, shape=(N, 16))       # LBG iterations as train_lbg runs them (fused pass)
 for _ in range(reps):
     eng.blocks_from_image(img, 4, 4)
 torch.cuda.synchronize()

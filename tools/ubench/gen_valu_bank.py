@@ -264,8 +264,10 @@ int main() {
             }
             double winst = (double)iters * 64;
             double shader_ghz = h[1] ? (double)h[0] / (double)h[1] * 0.1 : 0.0;   // memrealtime ticks at 100 MHz
-            // SIMD cycles per wave-instruction: wave 0's own cycle count / its instructions / waves sharing the SIMD
-            double cyc = (double)h[0] / winst / wps;
+            // SIMD cycles per wave-instruction from the wall time: the launch's duration in shader cycles over the
+            // wave-instructions one SIMD issued (wps waves of `winst` each).  (A wave's own cycle counter does not serve:
+            // the oldest wave of a SIMD wins the arbitration and always sees its own, unshared rate.)
+            double cyc = (double)best * 1e-3 * shader_ghz * 1e9 / (winst * wps);
             printf("%-52s %6d %10.4f %12.3f %10.3f\n", f.name, wps, best, shader_ghz, cyc);
         }
         fflush(stdout);
