@@ -36,10 +36,15 @@ def setup(which):
         img = bench.iid_image(8192, 8192, 1, dev)
         bh, K = 4, 256
         crop = img[:1024, :1024].contiguous()
-    elif which == "rgb48":
-        img = bench.structured_image(4096, 4096, 3, dev, channels=3)
+    elif which in ("rgb48", "rgb48big"):
+        side = 8192 if which == "rgb48big" else 4096
+        img = bench.structured_image(side, side, 3, dev, channels=3)
         bh, K = 4, 256
         crop = img[:1024, :1024].contiguous()
+    elif which == "g64":                                       # grayscale 8x8 blocks: 64-byte rows
+        img = bench.structured_image(8192, 8192, 7, dev)
+        bh, K = 8, 256
+        crop = img[:2048, :2048].contiguous()
     elif which == "cfg5":
         img = bench.structured_image(4096, 4096, 5, dev, channels=3)
         bh, K = 8, 4096

@@ -1796,8 +1796,8 @@ struct AssignArgs {
                                 // the 64-bit word at qcount[16 * q + 2] collects the pairs evaluated (statistics)
     uint32_t qcap;
     unsigned long long *acc_rep; // ACC: NREP replicas of the [K][d+1] table of [sums | count], zeroed before the launch
-    int vec4;                   // 1: rows may be read as aligned 32-bit words (d % 4 == 0, base 4-byte aligned);
-                                // 2: rows are exactly 16 bytes and 16-byte aligned
+    int vec4;                   // how a vector is read: 0 byte by byte, 1 word by word, 2 in 16-byte pieces
+                                // (row_load_mode)
     int64_t ntiles;
     // PRUNE: the search reads the window-sorted copy of the vectors and skips codewords by element sum
     const uint8_t *rows;        // N * d bytes: the vectors, each window of SORT_WIN sorted by element sum
@@ -1944,13 +1944,16 @@ __global__ __launch_bounds__(ACC ? 1024 : 512) VQ_ASSIGN_ATTR void k_assign_fast
             origin[r] = PRUNE ? (uint32_t)a.perm[n] : 0u;
             // Out-of-row positions (d below the template's padded size) are loaded from a clamped
             // index and zeroed later, so that no load sits behind a branch.
-            if (DP2 == 8 && a.vec4 == 2) {
-                // 16-byte rows, 16-byte aligned: one load per vector
-                const uint4 v = *reinterpret_cast<const uint4 *>(row);
-                x[r][0] = v.x;
-                x[r][2] = v.y;
-                x[r][4] = v.z;
-                x[r][6] = v.w;
+            if (DP2 % 8 == 0 && a.vec4 == 2) {
+                // rows of exactly 2 * DP2 bytes, 16-byte aligned: whole 16-byte pieces from one address
+#pragma unroll
+                for (int q = 0; q < DP2 / 8; ++q) {
+                    const uint4 v = reinterpret_cast<const uint4 *>(row)[q];
+                    x[r][8 * q] = v.x;
+                    x[r][8 * q + 2] = v.y;
+                    x[r][8 * q + 4] = v.z;
+                    x[r][8 * q + 6] = v.w;
+                }
             } else if (a.vec4) {
                 const uint32_t *row4 = reinterpret_cast<const uint32_t *>(row);
                 const int nw = d >> 2;
@@ -1965,6 +1968,9 @@ __global__ __launch_bounds__(ACC ? 1024 : 512) VQ_ASSIGN_ATTR void k_assign_fast
                     b0 = e0 < d ? b0 : 0u;
                     b1 = e1 < d ? b1 : 0u;
                     x[r][p] = (b0 | (b1 << 16)) << 8;
+                    // long rows: sixteen bytes on their way at a time (a register per byte of the whole row would set
+                    // the register count of the kernel)
+                    if (DP2 > 8 && p % 8 == 7) __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -2501,6 +2507,9 @@ __global__ __launch_bounds__(ACC ? 1024 : 512) VQ_ASSIGN_ATTR void k_assign_fast
                                 acc += fabs(xv - crow[e]);
                             }
                         }
+                        // long rows: at most eight codeword elements on their way at a time (all of them at once
+                        // would set the register count of the whole kernel)
+                        if (DP2 > 8 && p % 4 == 3) __builtin_amdgcn_sched_barrier(0);
                     }
                 };
                 // every lane reads another codeword: from global memory that is 64 cache lines per load instruction,
@@ -2518,6 +2527,8 @@ __global__ __launch_bounds__(ACC ? 1024 : 512) VQ_ASSIGN_ATTR void k_assign_fast
             // table and the LDS copy of the codebook are set up and flushed once per workgroup instead of once per
             // tile, and a wave that is done with a tile does not wait for the rest of its workgroup.  The counters
             // (word 4 of the first eight counter slots) are zeroed with the queue counters before the launch.
+            // (Measured for the plain search too, d = 16 and d = 48 at two to four rounds of workgroups: not faster,
+            // and the loop costs 14 to 20 vector registers.)
             looped = true;
             const uint32_t xcd = blockIdx.x & 7;
             uint32_t *ctr = a.qcount + 16 * xcd + 4;
@@ -3700,8 +3711,13 @@ int grid_for(int64_t work_items, int block, int max_blocks) {
 
 // Vectors per lane: the scalar-load variant serves d <= 32, the LDS variant everything.
 constexpr int r_lds_for(int dp2) { return dp2 <= 32 ? 4 : 2; }
-// Pruned search: rows beyond 32 bytes take two vectors per lane (registers).
-constexpr int r_prune_for(int dp2) { return dp2 <= 16 ? VQ_RP : 2; }
+// Pruned search by scalar loads: rows beyond 32 bytes take one vector per lane -- 60 instead of 91 vector registers at
+// 48 bytes, tiles of half the length (a launch of a few rounds of workgroups ends with less of the chip idle) and a
+// narrower range of element sums per wave (1 M vectors, K = 256: 48-byte rows 119 -> 111 us, 64-byte rows 139 -> 121 us).
+#ifndef VQ_RP_LONG
+#define VQ_RP_LONG 1
+#endif
+constexpr int r_prune_for(int dp2) { return dp2 <= 16 ? VQ_RP : VQ_RP_LONG; }
 
 // Events to record around the next search-kernel launch of the calling thread (vq_profile_next_search; one-shot).
 thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
@@ -4001,6 +4017,15 @@ bool fused_acc_supported(const void *sorted, int K, int d) {
            fused_acc_lds(K, d) <= 40 * 1024;
 }
 
+// How the search kernels read a vector (AssignArgs::vec4): 0 = byte by byte; 1 = word by word, the row ending anywhere
+// in the kernel's padded length; 2 = rows of exactly the padded length in 16-byte pieces (rows and base address
+// multiples of 16).
+int row_load_mode(const void *rows, int d, int dp2) {
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(rows);
+    if ((d & 3) != 0 || (addr & 3) != 0) return 0;
+    return (d == 2 * dp2 && (d & 15) == 0 && (addr & 15) == 0) ? 2 : 1;
+}
+
 // sums / counts non-null (only with fused_acc_supported): cluster sums are accumulated too.
 int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d, const double *cb, int K,
              int32_t *labels, double *min_dist, unsigned long long *sums, unsigned long long *counts, void *ws,
@@ -4063,8 +4088,7 @@ int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int
         if (!g_ws_zeroed) HIP_TRY(hipMemsetAsync(a.acc_rep, 0, (size_t)NREP * K * (d + 1) * 8, st));
     }
     a.ntiles = ntiles;
-    a.vec4 = ((d & 3) == 0) && ((reinterpret_cast<uintptr_t>(blocks) & 3) == 0);
-    if (d == 16 && (reinterpret_cast<uintptr_t>(blocks) & 15) == 0) a.vec4 = 2;     // whole 16-byte rows
+    a.vec4 = row_load_mode(blocks, d, dp2);
     a.rows = nullptr; a.perm = nullptr; a.shdr = nullptr;
     a.dist_sorted_end = (prune && dist_sorted) ? N / NP_CHUNK * NP_CHUNK : 0;
     a.cb_lds = acc_cb_lds ? 1 : 0;
@@ -4092,8 +4116,7 @@ int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int
         a.rows = reinterpret_cast<const uint8_t *>(sp + SL.rows);
         a.perm = reinterpret_cast<const uint16_t *>(sp + SL.perm);
         a.shdr = reinterpret_cast<const SortedHeader *>(sp + SL.hdr);
-        a.vec4 = ((d & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.rows) & 3) == 0);
-        if (d == 16 && (reinterpret_cast<uintptr_t>(a.rows) & 15) == 0) a.vec4 = 2;
+        a.vec4 = row_load_mode(a.rows, d, dp2);
         // a wave's vectors must come from one sort window; the LDS-tiled search needs that of a whole workgroup
         if (SORT_WIN % (lds_cw ? tile : (int64_t)WAVE * R) != 0)
             return fail(VQ_E_HIP, "internal: sort window %d is not a multiple of the tile %lld", SORT_WIN, (long long)tile);
