@@ -1941,7 +1941,11 @@ __global__ __launch_bounds__(ACC ? 1024 : 512) VQ_ASSIGN_ATTR void k_assign_fast
             int64_t n = vec_index(r);
             if (n >= a.N) n = a.N - 1;                 // clamp: loads stay in bounds, result is discarded
             const uint8_t *row = (PRUNE ? a.rows : a.blocks) + (size_t)n * d;
-            origin[r] = PRUNE ? (uint32_t)a.perm[n] : 0u;
+            // (the fused LBG pass of a training run writes no labels and leaves its distances in sorted order: it
+            // has no use for the origin map, except in the partial last chunk)
+            origin[r] = 0u;
+            if (PRUNE && (!ACC || a.labels != nullptr || base + wave_off + WAVE * R > a.dist_sorted_end))
+                origin[r] = (uint32_t)a.perm[n];
             // Out-of-row positions (d below the template's padded size) are loaded from a clamped
             // index and zeroed later, so that no load sits behind a branch.
             if (DP2 % 8 == 0 && a.vec4 == 2) {
