@@ -275,7 +275,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # (VQ_BENCH_FORCE_GROUP=1 under torchrun with one process: the multi-GPU code path -- RCCL collectives between the
+    # two halves of every LBG iteration -- on a single GPU, to measure what the exchange machinery itself costs)
+    distributed = world > 1 or os.environ.get("VQ_BENCH_FORCE_GROUP") == "1"
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     torch.cuda.set_device(local_rank)
@@ -384,7 +386,7 @@ def main():
              "subtract + |.|-accumulate ops (2*d per evaluated (vector, codeword) pair; pairs counted by the kernel "
              "itself: rows each wave evaluated x its 128 vectors) / the filter kernel's mean duration (HIP events "
              "recorded by the library right around that launch, on its stream). peak = the v_sad_u16 issue ceiling: one wave64 instruction per 4 cycles per "
-             "SIMD (measured, profiles/r02_valu_ubench_forms1.txt and _forms2.txt, column ms; no operand form issues faster), two |x-c| accumulations "
+             "SIMD (measured, profiles/r03_valu_ubench_forms1.txt and _forms2.txt, column ms; no operand form issues faster), two |x-c| accumulations "
              "per lane = 157.3 T ops/s. Besides its d/2 SADs every pair costs 3 more instructions of the same issue "
              "class per codeword pair (two keys, median, min3, min: 2.5 per codeword), so 8/10.5 = 0.76 is the ceiling of frac at d = 16; the kernel's time also "
              "holds the fp64 re-check of its near-ties (queued_for_fp64_frac of the vectors; there is no fix-up "
@@ -435,7 +437,8 @@ def main():
     lbg_elapsed = float(t.item())
     # the dominant kernel of an iteration alone: the pruned search with the per-cluster accumulation and the winners'
     # fp64 distances fused in (HIP events recorded by the library around that launch)
-    acc_ms = eng.search_kernel_ms(lambda: eng.lbg_accum(None, cb, sorted=srt, shape=(N, d)), 20)
+    # (as a training stage launches it: no labels written, distances left in sorted order)
+    acc_ms = eng.search_kernel_ms(lambda: eng.lbg_stage(None, cb, N, -1.0, 1, sorted=srt, shape=(N, d)), 20)
     _, acc_pairs = eng.search_statistics((cb, eng._workspace(K_CODEBOOK, d, N)), N)
     acc_ops = (2.0 * d) * float(acc_pairs) + float(d) * N        # SAD work of the evaluated pairs + d byte sums per vector
     lbg_roofline = dict(

@@ -205,22 +205,28 @@ int vq_lbg_iterate(const uint8_t *blocks, const void *sorted, size_t sorted_byte
 /* The same iteration for block vectors sharded over several GPUs (one process per GPU), split around the exchange so
  * that nothing returns to the host.  No counterpart in the reference (VQ_Full.py:76-98 is one process).
  * vq_lbg_iterate_local: this rank's part of VQ_Full.py:77-90 -- sums / counts of its N vectors (overwritten),
- * chunk_sums[0 .. ceil(N / 8192)) = the per-chunk sums of its winning distances (ceil(N / 8192) + 1 doubles of
- * room), local_total[0] = their left-to-right total.  vq_lbg_iterate_finish: given the sums / counts added over all
- * ranks and every rank's chunk sums (rank r's h_chunk_counts[r] <= width values at chunk_sums_all[r * width]; device
- * memory, e.g. the output of an all-gather; world <= 64), adds the chunk sums left to right in rank order -- bit for
- * bit the single-process distance sum when every rank but the last holds a multiple of 8192 vectors; ranks whose
- * shards are not aligned pass their local_total as a single value -- then updates cb in place and applies the stop
- * rule for `iteration` exactly as vq_lbg_iterate does.  Both calls carry the stage's gate: enqueued for an
+ * chunk_sums[0 .. ceil(N / 8192)) = the per-chunk sums of its winning distances, local_total[0] (nullable) = their
+ * left-to-right total.  The three outputs may point into one buffer that is then handed to an all-gather as it is.
+ * vq_lbg_iterate_finish: given the sums / counts of all ranks -- `records` = 1: already added up (an all-reduce);
+ * `records` = the number of ranks: one record per rank, record r at sums[r * record_stride] / counts[r * record_stride]
+ * (64-bit words; what an all-gather of [sums | counts | ...] leaves), added here -- and every rank's chunk sums (rank
+ * r's h_chunk_counts[r] <= chunk_stride values at chunk_sums_all[r * chunk_stride]; device memory; world <= 64), adds
+ * the chunk sums left to right in rank order -- bit for bit the single-process distance sum when every rank but the
+ * last holds a multiple of 8192 vectors; ranks whose shards are not aligned pass their local_total as a single value
+ * -- then updates cb in place and applies the stop rule for `iteration` exactly as vq_lbg_iterate does.  ws (nullable):
+ * the workspace the calling thread gave vq_lbg_iterate_local for this iteration; with it, for the shapes of the
+ * one-workgroup preparation (d <= 16, K <= 512), the updated codebook is prepared for the next iteration in the same
+ * launch and the next vq_lbg_iterate_local skips that step.  Both calls carry the stage's gate: enqueued for an
  * iteration past the one that converged they leave cb and the records untouched (the collectives between them
  * still run, on every rank alike).  labels as in vq_lbg_iterate (nullable when vq_lbg_pass_fused). */
 int vq_lbg_iterate_local(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d, const double *cb,
                          int K, int iteration, uint64_t *sums, uint64_t *counts, double *chunk_sums, double *local_total,
                          int32_t *labels, double *min_dist, int mode, void *state, size_t state_bytes, void *ws,
                          size_t ws_bytes, void *stream);
-int vq_lbg_iterate_finish(const uint64_t *sums, const uint64_t *counts, const double *chunk_sums_all, int world, int width,
-                          const int *h_chunk_counts, double *cb, int K, int d, int64_t n_total, double threshold,
-                          int iteration, void *state, size_t state_bytes, void *stream);
+int vq_lbg_iterate_finish(const uint64_t *sums, const uint64_t *counts, int records, int64_t record_stride,
+                          const double *chunk_sums_all, int world, int64_t chunk_stride, const int *h_chunk_counts, double *cb,
+                          int K, int d, int64_t n_total, double threshold, int iteration, void *state, size_t state_bytes,
+                          void *ws, size_t ws_bytes, void *stream);
 
 /* Sum of an fp64 vector in the order numpy.add.reduce uses on a contiguous array (what np.mean
  * does before dividing, VQ_Full.py:90): pairwise summation -- runs of up to 128 elements with

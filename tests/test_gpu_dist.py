@@ -183,11 +183,14 @@ def _p(t):
 
 @pytest.mark.parametrize("cuts", [(8192, 2 * 8192), (8192, 8192), (5000, 20000), (0, 3 * 8192)])
 @pytest.mark.parametrize("K", [32, 64])
-def test_iterate_local_and_finish_equal_one_process(cuts, K, oracle):
+@pytest.mark.parametrize("layout", ["reduced", "gathered"])
+def test_iterate_local_and_finish_equal_one_process(cuts, K, layout, oracle):
     """vq_lbg_iterate_local on three shards (one GPU, one after the other, each with its own workspace and state),
-    the exchange done by hand (sums added, chunk sums laid out rank by rank), vq_lbg_iterate_finish on every
-    "rank": codebook and distortion record equal vq_lbg_iterate on all vectors -- bit for bit when the shards are
-    8192-aligned -- and the CPU oracle's iteration.  Covers an empty shard and shards that are not aligned."""
+    the exchange done by hand, vq_lbg_iterate_finish: codebook and distortion record equal vq_lbg_iterate on all
+    vectors -- bit for bit when the shards are 8192-aligned -- and the CPU oracle's iteration.  Covers an empty shard
+    and shards that are not aligned.  layout "reduced": sums added up beforehand, chunk sums laid out rank by rank (an
+    all-reduce plus an all-gather); "gathered": every rank's [sums | counts | chunk sums] written by the local call
+    straight into its row of one buffer, which the finish call reads as it is (one all-gather)."""
     import ctypes
     from vector_quantization_amd import HipEngine
     from vector_quantization_amd._lib import lib, check
@@ -220,6 +223,9 @@ def test_iterate_local_and_finish_equal_one_process(cuts, K, oracle):
                              None, _p(dist1), 1, _p(st1), nst, _p(ws1), ws1.numel(), stream), "vq_lbg_iterate")
     # the sharded iteration
     width = max(1, max(-(-n // 8192) for n in sizes)) if aligned else 1
+    nacc = K * d + K
+    gathered = torch.zeros((3, nacc + width), dtype=torch.int64, device=dev)
+    scratch_chunks = torch.zeros(-(-N // 8192) + 1, dtype=torch.float64, device=dev)
     accs, tails = [], []
     for r in range(3):
         n = sizes[r]
@@ -233,6 +239,18 @@ def test_iterate_local_and_finish_equal_one_process(cuts, K, oracle):
         dist_r = torch.empty(max(n, 1), dtype=torch.float64, device=dev)
         lab_r = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
         ws = torch.empty(lib.vq_workspace_bytes(K, d, n), dtype=torch.uint8, device=dev)
+        if layout == "gathered":
+            # the outputs go straight into this rank's row: [sums | counts | chunk sums or the local total]
+            row = gathered[r]
+            row_tail = row[nacc:].view(torch.float64)
+            check(lib.vq_lbg_iterate_local(_p(sh) if n else None, _p(srt_r), srt_r.numel() if n else 0, n, d, _p(cb_r), K, 0,
+                                           _p(row[:K * d]), _p(row[K * d:nacc]),
+                                           _p(row_tail) if aligned else _p(scratch_chunks),
+                                           None if aligned else _p(row_tail), _p(lab_r), _p(dist_r), 1,
+                                           _p(st_r), nst, _p(ws), ws.numel(), stream), "vq_lbg_iterate_local")
+            acc.copy_(row[:nacc])
+            accs.append(acc)
+            continue
         check(lib.vq_lbg_iterate_local(_p(sh) if n else None, _p(srt_r), srt_r.numel() if n else 0, n, d, _p(cb_r), K, 0,
                                        _p(acc[:K * d]), _p(acc[K * d:]), _p(chunk), _p(total), _p(lab_r), _p(dist_r), 1,
                                        _p(st_r), nst, _p(ws), ws.numel(), stream), "vq_lbg_iterate_local")
@@ -244,12 +262,18 @@ def test_iterate_local_and_finish_equal_one_process(cuts, K, oracle):
             t[0] = total[0]
         tails.append(t)
     acc_total = torch.stack(accs).sum(dim=0)
-    chunks_all = torch.stack(tails).contiguous()
     counts = (ctypes.c_int * 3)(*[(-(-n // 8192) if aligned else 1) for n in sizes])
     cb2 = torch.from_numpy(cb_h).to(dev)
     st2, _ = state_buf()
-    check(lib.vq_lbg_iterate_finish(_p(acc_total[:K * d]), _p(acc_total[K * d:]), _p(chunks_all), 3, width, counts, _p(cb2),
-                                    K, d, N, 0.001, 0, _p(st2), nst, stream), "vq_lbg_iterate_finish")
+    if layout == "gathered":
+        stride = nacc + width
+        check(lib.vq_lbg_iterate_finish(_p(gathered[0, :K * d]), _p(gathered[0, K * d:nacc]), 3, stride,
+                                        _p(gathered[0, nacc:]), 3, stride, counts, _p(cb2), K, d, N, 0.001, 0, _p(st2), nst,
+                                        None, 0, stream), "vq_lbg_iterate_finish")
+    else:
+        chunks_all = torch.stack(tails).contiguous()
+        check(lib.vq_lbg_iterate_finish(_p(acc_total[:K * d]), _p(acc_total[K * d:]), 1, 0, _p(chunks_all), 3, width, counts,
+                                        _p(cb2), K, d, N, 0.001, 0, _p(st2), nst, None, 0, stream), "vq_lbg_iterate_finish")
     torch.cuda.synchronize(dev)
     assert torch.equal(acc_total, acc1)
     assert torch.equal(cb2, cb1)
@@ -261,6 +285,54 @@ def test_iterate_local_and_finish_equal_one_process(cuts, K, oracle):
         assert np.isclose(rec1, rec2, rtol=1e-12, atol=0)
     ref = oracle.lbg_iter(blocks_h, cb_h)
     assert np.array_equal(cb1.cpu().numpy(), ref["cb_out"]) and rec1 == ref["distortion"]
+
+
+@pytest.mark.parametrize("K", [64, 256, 1024])
+def test_iterate_local_finish_chain_prepares_the_next_iteration(K):
+    """Three iterations as vq_lbg_iterate_local + vq_lbg_iterate_finish (one rank, the finish call given the
+    workspace, so that it prepares the next iteration's codebook where the shape allows) against three calls of
+    vq_lbg_iterate: codebooks and all records identical."""
+    import ctypes
+    from vector_quantization_amd import HipEngine
+    from vector_quantization_amd._lib import lib, check
+    dev = torch.device("cuda:0")
+    eng = HipEngine(dev)
+    blocks_h = _make_blocks()
+    N, d = blocks_h.shape
+    rng = np.random.default_rng(6)
+    cb_h = np.clip(blocks_h[rng.choice(N, K, replace=False)].astype(np.float64) + rng.normal(0, 0.3, (K, d)), 0, 255)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    blocks = torch.from_numpy(blocks_h).to(dev)
+    srt = eng.sort_blocks(blocks)
+    nst = lib.vq_lbg_state_bytes(3)
+    nacc = K * d + K
+    nch = -(-N // 8192)
+    out = []
+    for split in (False, True):
+        cb = torch.from_numpy(cb_h).to(dev)
+        st = torch.empty(nst, dtype=torch.uint8, device=dev)
+        check(lib.vq_lbg_stage_begin(_p(st), nst, 3, stream), "stage_begin")
+        row = torch.zeros(nacc + nch, dtype=torch.int64, device=dev)
+        dist_b = torch.empty(N, dtype=torch.float64, device=dev)
+        lab = torch.empty(N, dtype=torch.int32, device=dev)
+        ws = torch.empty(lib.vq_workspace_bytes(K, d, N), dtype=torch.uint8, device=dev)
+        counts = (ctypes.c_int * 1)(nch)
+        for it in range(3):
+            if split:
+                check(lib.vq_lbg_iterate_local(None, _p(srt), srt.numel(), N, d, _p(cb), K, it, _p(row[:K * d]),
+                                               _p(row[K * d:nacc]), _p(row[nacc:]), None, _p(lab), _p(dist_b), 1, _p(st), nst,
+                                               _p(ws), ws.numel(), stream), "vq_lbg_iterate_local")
+                check(lib.vq_lbg_iterate_finish(_p(row[:K * d]), _p(row[K * d:nacc]), 1, 0, _p(row[nacc:]), 1, nch, counts,
+                                                _p(cb), K, d, N, -1.0, it, _p(st), nst, _p(ws), ws.numel(), stream),
+                      "vq_lbg_iterate_finish")
+            else:
+                check(lib.vq_lbg_iterate(None, _p(srt), srt.numel(), N, d, _p(cb), K, N, -1.0, it, _p(row[:K * d]),
+                                         _p(row[K * d:nacc]), _p(lab), _p(dist_b), 1, _p(st), nst, _p(ws), ws.numel(), stream),
+                      "vq_lbg_iterate")
+        torch.cuda.synchronize(dev)
+        out.append((cb.cpu().numpy(), st[64:64 + 48].cpu().numpy().tobytes()))
+    assert np.array_equal(out[0][0], out[1][0])
+    assert out[0][1] == out[1][1]
 
 
 def _batch_images(n_images=16, side=512):

@@ -20,7 +20,7 @@ VQ_MODE_FAST = 1
 VQ_PAD_EDGE = 0
 VQ_PAD_ZERO = 1
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -55,7 +55,8 @@ SIGNATURES = {
     "vq_lbg_stage_begin": (_i, [_vp, _sz, _i, _vp]),
     "vq_lbg_iterate": (_i, [_vp, _vp, _sz, _i64, _i, _vp, _i, _i64, _dbl, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _sz, _vp]),
     "vq_lbg_iterate_local": (_i, [_vp, _vp, _sz, _i64, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _sz, _vp]),
-    "vq_lbg_iterate_finish": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i64, _dbl, _i, _vp, _sz, _vp]),
+    "vq_lbg_iterate_finish": (_i, [_vp, _vp, _i, _i64, _vp, _i, _i64, _vp, _vp, _i, _i, _i64, _dbl, _i, _vp, _sz, _vp, _sz,
+                                   _vp]),
     "vq_sorted_forget": (_i, [_vp]),
     "vq_numpy_sum_f64": (_i, [_vp, _i64, _vp, _vp, _vp]),
     "vq_accum_labels": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp, _vp]),

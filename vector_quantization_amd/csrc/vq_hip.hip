@@ -84,7 +84,7 @@ int fail(int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(VQ_E_HIP, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
     } while (0)
 
-constexpr int ABI_VERSION = 6;
+constexpr int ABI_VERSION = 7;
 constexpr int WAVE = 64;
 constexpr int64_t NP_CHUNK = 8192;      // numpy's reduction buffer: elements per pairwise-summed chunk
 constexpr int MAX_D_FAST = 192;         // largest vector dimension of the SAD filter kernels
@@ -3124,6 +3124,21 @@ __global__ __launch_bounds__(512) void k_npsum_chunks(const double *__restrict__
     for (int64_t c = blockIdx.x; c < nfull; c += gridDim.x) npsum_chunk(v, c, chunk_sums, s_leaf);
 }
 
+// total + s[0] + s[1] + ... + s[cnt - 1], added strictly left to right by the calling thread (s in LDS).  The values
+// are fetched eight at a time ahead of the additions that use them: one LDS round trip per addition otherwise.
+__device__ __forceinline__ double add_left_to_right(double total, const double *s, int cnt) {
+    int j = 0;
+    for (; j + 8 <= cnt; j += 8) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = s[j + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) total += v[k];
+    }
+    for (; j < cnt; ++j) total += s[j];
+    return total;
+}
+
 // One workgroup of BLOCK threads: the trailing partial chunk (m = N mod 8192 elements, numpy's uneven recursive
 // halving reproduced with an explicit stack), then the left-to-right sum over all chunk sums, returned in
 // thread 0.
@@ -3203,7 +3218,7 @@ __device__ __forceinline__ double npsum_final_block(const double *__restrict__ v
         __syncthreads();
         if (threadIdx.x == 0) {
             const int cnt = (int)(nchunks - lo < BLOCK ? nchunks - lo : BLOCK);
-            for (int j = 0; j < cnt; ++j) total += s_buf[j];
+            total = add_left_to_right(total, s_buf, cnt);
         }
         __syncthreads();
     }
@@ -3315,41 +3330,55 @@ __global__ __launch_bounds__(1024) void k_lbg_finish_t(const double *__restrict_
 }
 
 // The tail of an LBG iteration whose vectors are sharded over several ranks (one workgroup): the ranks' per-chunk
-// distance sums -- rank r's count[r] values at chunks_all[r * width] -- added left to right in rank order (what one
+// distance sums -- rank r's count[r] values at chunks_all[r * stride] -- added left to right in rank order (what one
 // process computes on the concatenated vectors when every shard but the last is a whole number of chunks), then the
-// centroid update in place from the reduced sums / counts and the stop rule (VQ_Full.py:81-98).
+// centroid update in place from the sums / counts (already reduced, or one record per rank) and the stop rule
+// (VQ_Full.py:81-98); TPC > 0: then the codebook preparation of the next iteration, as in k_lbg_finish_t.
 constexpr int MAX_RANKS = 64;
 struct RankChunks {
-    int world, width;
+    int world;
+    int64_t stride;
     int count[MAX_RANKS];
 };
-__global__ __launch_bounds__(1024) void k_lbg_finish_ranks(const double *__restrict__ chunks_all, const RankChunks rc,
-                                                           const unsigned long long *__restrict__ sums,
-                                                           const unsigned long long *__restrict__ counts, double *cb, int K,
-                                                           int d, double n_total, double threshold, LbgState *state, Gate g) {
+template <int TPC>
+__global__ __launch_bounds__(1024) void k_lbg_finish_ranks_t(const double *__restrict__ chunks_all, const RankChunks rc,
+                                                             const unsigned long long *__restrict__ sums,
+                                                             const unsigned long long *__restrict__ counts, int records,
+                                                             int64_t record_stride, double *cb, int K, int d, double n_total,
+                                                             double threshold, LbgState *state, Gate g, PrepArgs pa) {
+    extern __shared__ __align__(16) unsigned long long s_prepkeys[];
     __shared__ double s_buf[1024];
     if (gate_closed(g)) return;
     double total = 0.0;
     for (int r = 0; r < rc.world; ++r) {
-        const double *cs = chunks_all + (size_t)r * rc.width;
+        const double *cs = chunks_all + (size_t)r * rc.stride;
         for (int lo = 0; lo < rc.count[r]; lo += 1024) {
             const int i = lo + (int)threadIdx.x;
             s_buf[threadIdx.x] = i < rc.count[r] ? cs[i] : 0.0;
             __syncthreads();
             if (threadIdx.x == 0) {
                 const int cnt = rc.count[r] - lo < 1024 ? rc.count[r] - lo : 1024;
-                for (int j = 0; j < cnt; ++j) total += s_buf[j];
+                total = add_left_to_right(total, s_buf, cnt);
             }
             __syncthreads();
         }
     }
+    // the ranks' integer sums and counts (records > 1: as an all-gather left them, record_stride words apart)
     for (int i = threadIdx.x; i < K * d; i += 1024) {
-        const unsigned long long c = counts[i / d];
-        if (c) cb[i] = (double)sums[i] / (double)c;
+        unsigned long long c = 0, sm = 0;
+        for (int r = 0; r < records; ++r) {
+            c += counts[(size_t)r * record_stride + i / d];
+            sm += sums[(size_t)r * record_stride + i];
+        }
+        if (c) cb[i] = (double)sm / (double)c;
     }
     if (threadIdx.x == 0) {
         state->dist_sum = total;
         apply_stop_rule(state, total, n_total, threshold, g.iter);
+    }
+    if constexpr (TPC > 0) {
+        __syncthreads();                                       // the updated codebook is visible to the whole workgroup
+        prepare_small_body<TPC>(cb, K, d, pa.dp2, pa.clim, pa.hdr, pa.c16, pa.bias, pa.cbT, pa.postab, s_prepkeys);
     }
 }
 
@@ -4716,7 +4745,7 @@ int lbg_iterate_impl(const uint8_t *blocks, const void *sorted, size_t sorted_by
         return fail(VQ_E_INVALID, "iteration %d is outside the state buffer (%zu bytes)", iteration, state_bytes);
     if (finish && (n_total < 1 || N > n_total)) return fail(VQ_E_INVALID, "need n_total >= max(N, 1)");
     if (!sums || !counts || !cb) return fail(VQ_E_INVALID, "null sums, counts or codebook pointer");
-    if (!finish && (!chunk_out || !total_out)) return fail(VQ_E_INVALID, "null chunk_sums or local_total pointer");
+    if (!finish && !chunk_out) return fail(VQ_E_INVALID, "null chunk_sums pointer");
     if (K <= 0 || d <= 0) return fail(VQ_E_INVALID, "need K > 0 and d > 0");
     hipStream_t st = static_cast<hipStream_t>(stream);
     LbgState *S = static_cast<LbgState *>(state);
@@ -4797,9 +4826,10 @@ int lbg_iterate_impl(const uint8_t *blocks, const void *sorted, size_t sorted_by
                 hipLaunchKernelGGL(k_lbg_finish_t<2>, dim3(1), dim3(1024), hash_lds, st, min_dist, N, nfull, chunk_sums, s64,
                                    c64, cb, K, d, (double)n_total, threshold, S, g_gate, pa);
             LAUNCH_CHECK("k_lbg_finish");
-        } else {
+        } else if (total_out || N % NP_CHUNK != 0) {
             // the trailing partial chunk and the total of this call's chunk sums
-            hipLaunchKernelGGL(k_npsum_final, dim3(1), dim3(1024), 0, st, min_dist, N, nfull, chunk_sums, total_out);
+            hipLaunchKernelGGL(k_npsum_final, dim3(1), dim3(1024), 0, st, min_dist, N, nfull, chunk_sums,
+                               total_out ? total_out : &S->dist_sum);
             LAUNCH_CHECK("k_npsum_final");
         }
         g_tail_left = TailLeft{ws, state, iteration, K, d, N, prep_next};
@@ -4835,7 +4865,7 @@ int lbg_iterate_impl(const uint8_t *blocks, const void *sorted, size_t sorted_by
         }
     }
     rc = vq_lbg_accum(blocks, sorted, sorted_bytes, N, d, cb, K, sums, counts, labels, min_dist,
-                      finish ? &S->dist_sum : total_out, chunk_out, mode, ws, ws_bytes, stream);
+                      (finish || !total_out) ? &S->dist_sum : total_out, chunk_out, mode, ws, ws_bytes, stream);
     if (rc) return rc;
     if (finish) {
         hipLaunchKernelGGL(k_finalize_rule, dim3(grid_for((int64_t)K * d, 256, 4096)), dim3(256), 0, st,
@@ -4864,30 +4894,71 @@ int vq_lbg_iterate_local(const uint8_t *blocks, const void *sorted, size_t sorte
                             labels, min_dist, mode, state, state_bytes, ws, ws_bytes, stream, chunk_sums, local_total, false);
 }
 
-int vq_lbg_iterate_finish(const uint64_t *sums, const uint64_t *counts, const double *chunk_sums_all, int world, int width,
-                          const int *h_chunk_counts, double *cb, int K, int d, int64_t n_total, double threshold,
-                          int iteration, void *state, size_t state_bytes, void *stream) {
+int vq_lbg_iterate_finish(const uint64_t *sums, const uint64_t *counts, int records, int64_t record_stride,
+                          const double *chunk_sums_all, int world, int64_t chunk_stride, const int *h_chunk_counts, double *cb,
+                          int K, int d, int64_t n_total, double threshold, int iteration, void *state, size_t state_bytes,
+                          void *ws, size_t ws_bytes, void *stream) {
     if (!state) return fail(VQ_E_INVALID, "null state pointer");
     if (iteration < 0 || state_bytes < vq_lbg_state_bytes(iteration + 1))
         return fail(VQ_E_INVALID, "iteration %d is outside the state buffer (%zu bytes)", iteration, state_bytes);
     if (!sums || !counts || !cb || !chunk_sums_all || !h_chunk_counts) return fail(VQ_E_INVALID, "null pointer");
     if (K <= 0 || d <= 0 || n_total < 1) return fail(VQ_E_INVALID, "need K > 0, d > 0, n_total >= 1");
     if (world < 1 || world > MAX_RANKS) return fail(VQ_E_UNSUPPORTED, "world=%d is outside 1 .. %d", world, MAX_RANKS);
-    if (width < 1) return fail(VQ_E_INVALID, "need width >= 1");
+    if (records < 1 || records > MAX_RANKS) return fail(VQ_E_INVALID, "records=%d is outside 1 .. %d", records, MAX_RANKS);
+    if (records > 1 && record_stride < (int64_t)K * d) return fail(VQ_E_INVALID, "record_stride is shorter than a record");
+    if (chunk_stride < 1) return fail(VQ_E_INVALID, "need chunk_stride >= 1");
     RankChunks rcs;
     rcs.world = world;
-    rcs.width = width;
+    rcs.stride = chunk_stride;
     for (int r = 0; r < MAX_RANKS; ++r) rcs.count[r] = 0;
     for (int r = 0; r < world; ++r) {
-        if (h_chunk_counts[r] < 0 || h_chunk_counts[r] > width)
-            return fail(VQ_E_INVALID, "rank %d has %d chunk sums, the rows hold %d", r, h_chunk_counts[r], width);
+        if (h_chunk_counts[r] < 0 || h_chunk_counts[r] > chunk_stride)
+            return fail(VQ_E_INVALID, "rank %d has %d chunk sums, the rows are %lld apart", r, h_chunk_counts[r],
+                        (long long)chunk_stride);
         rcs.count[r] = h_chunk_counts[r];
     }
     LbgState *S = static_cast<LbgState *>(state);
-    hipLaunchKernelGGL(k_lbg_finish_ranks, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), chunk_sums_all, rcs,
-                       reinterpret_cast<const unsigned long long *>(sums), reinterpret_cast<const unsigned long long *>(counts),
-                       cb, K, d, (double)n_total, threshold, S, Gate{&S->stopped_after, iteration});
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // With the workspace of this thread's vq_lbg_iterate_local of the same iteration, the one-workgroup codebook
+    // preparation of the next iteration rides on this launch (the shapes it serves), and the next
+    // vq_lbg_iterate_local skips its own.
+    const TailLeft left = g_tail_left;                         // (check_ws forgets it)
+    const bool same = ws != nullptr && left.ws == ws && left.state == state && left.iteration == iteration && left.K == K &&
+                      left.d == d;
+    PrepArgs pa = {};
+    bool prep_next = false;
+    if (ws) {
+        int rc = check_ws(ws, ws_bytes, K, d, 0);
+        if (rc) return rc;
+        prep_next = same && d <= 16 && K <= 512;
+        const WsLayout L0 = ws_layout(K, d, 0);
+        char *w = static_cast<char *>(ws);
+        pa.dp2 = dp2_bucket(d);
+        pa.clim = key_layout(K, pa.dp2).clim;
+        pa.hdr = reinterpret_cast<PrepHeader *>(w + L0.header);
+        pa.c16 = reinterpret_cast<uint32_t *>(w + L0.c16);
+        pa.bias = reinterpret_cast<uint32_t *>(w + L0.bias);
+        pa.postab = reinterpret_cast<uint32_t *>(w + L0.postab);
+        pa.cbT = reinterpret_cast<double *>(w + L0.cbT);
+    }
+    const unsigned long long *s64 = reinterpret_cast<const unsigned long long *>(sums);
+    const unsigned long long *c64 = reinterpret_cast<const unsigned long long *>(counts);
+    const Gate gate{&S->stopped_after, iteration};
+    const size_t hash_lds = (K <= PREP_HASH_CAP && K > 1) ? (size_t)K * 32 : 16;
+    if (!prep_next)
+        hipLaunchKernelGGL(k_lbg_finish_ranks_t<0>, dim3(1), dim3(1024), 0, st, chunk_sums_all, rcs, s64, c64, records,
+                           record_stride, cb, K, d, (double)n_total, threshold, S, gate, pa);
+    else if (K <= 256)
+        hipLaunchKernelGGL(k_lbg_finish_ranks_t<4>, dim3(1), dim3(1024), hash_lds, st, chunk_sums_all, rcs, s64, c64, records,
+                           record_stride, cb, K, d, (double)n_total, threshold, S, gate, pa);
+    else
+        hipLaunchKernelGGL(k_lbg_finish_ranks_t<2>, dim3(1), dim3(1024), hash_lds, st, chunk_sums_all, rcs, s64, c64, records,
+                           record_stride, cb, K, d, (double)n_total, threshold, S, gate, pa);
     LAUNCH_CHECK("k_lbg_finish_ranks");
+    if (same) {
+        g_tail_left = left;
+        g_tail_left.prepared = prep_next;
+    }
     return VQ_OK;
 }
 

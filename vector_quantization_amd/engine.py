@@ -359,22 +359,20 @@ class HipEngine:
         nstate = lib.vq_lbg_state_bytes(int(limit))
         state = torch.empty(nstate, dtype=torch.uint8, device=self.device)
         nacc = K * d + K
-        acc = torch.empty(nacc, dtype=torch.int64, device=self.device)
         nch = -(-N // 8192)
-        chunk = torch.zeros(nch + 1, dtype=torch.float64, device=self.device)
-        total = torch.zeros(1, dtype=torch.float64, device=self.device)
         width = max(1, max(-(-n // 8192) for n in sizes)) if aligned else 1
         counts_h = (ctypes.c_int * world)(*[(-(-n // 8192) if aligned else 1) for n in sizes])
+        # This rank's record [sums | counts | chunk sums (or the local total)]: the local half writes it in place, an
+        # all-gather moves it as it is, the finishing half reads every rank's record where the all-gather left it.
+        row = nacc + width
+        record = torch.zeros(row, dtype=torch.int64, device=self.device)
+        tail = record[nacc:].view(torch.float64)
+        unaligned_chunks = None if aligned else torch.zeros(nch + 1, dtype=torch.float64, device=self.device)
         small = nacc * 8 * world <= allreduce_from_bytes
         if small:
-            payload = torch.zeros(nacc + width, dtype=torch.int64, device=self.device)
-            tail = payload[nacc:].view(torch.float64)
-            gathered = torch.empty((world, nacc + width), dtype=torch.int64, device=self.device)
-            acc_total = torch.empty(nacc, dtype=torch.int64, device=self.device)
+            gathered = torch.empty((world, row), dtype=torch.int64, device=self.device)
         else:
-            payload, gathered, acc_total = None, None, acc
-            tail = torch.zeros(width, dtype=torch.float64, device=self.device)
-        chunks_all = torch.empty((world, width), dtype=torch.float64, device=self.device)
+            chunks_all = torch.empty((world, width), dtype=torch.float64, device=self.device)
         if self._scratch_n < N:
             self._labels_scratch = torch.empty(N, dtype=torch.int32, device=self.device)
             self._dist_scratch = torch.empty(N, dtype=torch.float64, device=self.device)
@@ -389,25 +387,24 @@ class HipEngine:
         def enqueue(j):
             with torch.cuda.device(self.device):
                 check(lib.vq_lbg_iterate_local(_ptr(blocks), _ptr(sorted), _nbytes(sorted), N, d, _ptr(cb), K, j,
-                                               _ptr(acc[: K * d]), _ptr(acc[K * d:]), _ptr(chunk), _ptr(total), _ptr(lab),
+                                               _ptr(record[: K * d]), _ptr(record[K * d: nacc]),
+                                               _ptr(tail) if aligned else _ptr(unaligned_chunks),
+                                               None if aligned else _ptr(tail), _ptr(lab),
                                                _ptr(self._dist_scratch), use_mode, _ptr(state), nstate, _ptr(ws), ws.numel(),
                                                self._stream()), "vq_lbg_iterate_local")
-                if aligned:
-                    if nch:
-                        tail[:nch].copy_(chunk[:nch])
-                else:
-                    tail[:1].copy_(total)
                 if small:
-                    payload[:nacc].copy_(acc)
-                    dist.all_gather_into_tensor(gathered.view(-1), payload, group=group)
-                    torch.sum(gathered[:, :nacc], dim=0, out=acc_total)     # integers: any order gives the same sums
-                    chunks_all.copy_(gathered[:, nacc:].view(torch.float64))
+                    dist.all_gather_into_tensor(gathered.view(-1), record, group=group)
+                    check(lib.vq_lbg_iterate_finish(_ptr(gathered[0, : K * d]), _ptr(gathered[0, K * d: nacc]), world, row,
+                                                    _ptr(gathered[0, nacc:]), world, row, counts_h, _ptr(cb), K, d,
+                                                    int(n_total), float(threshold), j, _ptr(state), nstate, _ptr(ws),
+                                                    ws.numel(), self._stream()), "vq_lbg_iterate_finish")
                 else:
-                    dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
                     dist.all_gather_into_tensor(chunks_all.view(-1), tail, group=group)
-                check(lib.vq_lbg_iterate_finish(_ptr(acc_total[: K * d]), _ptr(acc_total[K * d:]), _ptr(chunks_all), world,
-                                                width, counts_h, _ptr(cb), K, d, int(n_total), float(threshold), j,
-                                                _ptr(state), nstate, self._stream()), "vq_lbg_iterate_finish")
+                    dist.all_reduce(record[:nacc], op=dist.ReduceOp.SUM, group=group)   # integers: any order, same sums
+                    check(lib.vq_lbg_iterate_finish(_ptr(record[: K * d]), _ptr(record[K * d: nacc]), 1, 0, _ptr(chunks_all),
+                                                    world, width, counts_h, _ptr(cb), K, d, int(n_total), float(threshold),
+                                                    j, _ptr(state), nstate, _ptr(ws), ws.numel(), self._stream()),
+                          "vq_lbg_iterate_finish")
             return self._mark()
 
         distortions, conv = self._drive_stage(enqueue, state, limit)
