@@ -499,10 +499,18 @@ def main():
         cb48 = train_lbg(eng, eng.blocks_from_image(rgb[:1024, :1024].contiguous(), 4, 4), 256, log=None).codebook
         shapes["rgb4x4_K256_d48"] = search_profile(eng, rgb, 4, 4, cb48, 20, device)[0]
         del rgb
+        # the same shape at four times the vectors: a launch of many rounds of workgroups instead of fewer than three
+        # (what is left of a launch when the dispatcher runs out of workgroups weighs less)
+        rgb = structured_image(8192, 8192, 3, device, channels=3)
+        shapes["rgb4x4_K256_d48_4M_vectors"] = search_profile(eng, rgb, 4, 4, cb48, 10, device)[0]
+        del rgb
         # configs[4]: RGB 8x8 blocks, d = 192, K = 4096 (one GPU's share: 4096 x 4096 x 3, N = 262 144)
         rgb8 = structured_image(4096, 4096, 5, device, channels=3)
         cb192 = train_lbg(eng, eng.blocks_from_image(rgb8[:1024, :1024].contiguous(), 8, 8), 4096, log=None).codebook
         shapes["cfg5_K4096_d192"] = search_profile(eng, rgb8, 8, 8, cb192, 5, device)[0]
+        # four GPU shares in one call (N = 1 048 576): four workgroups per compute unit instead of one
+        rgb8 = structured_image(8192, 8192, 5, device, channels=3)
+        shapes["cfg5_K4096_d192_1M_vectors"] = search_profile(eng, rgb8, 8, 8, cb192, 3, device)[0]
         del rgb8
         result["shapes"] = shapes
         # configs[2]: full LBG training to K = 1024 on a 16384 x 16384 image (N = 16 777 216), one GPU

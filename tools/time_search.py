@@ -28,9 +28,9 @@ def med(fn, n=30):
 
 
 def setup(which):
-    if which in ("cfg2", "lbg", "k1024"):
+    if which in ("cfg2", "lbg", "k1024", "k4096"):
         img = bench.structured_image(8192, 8192, 1000, dev)
-        bh, K = 4, (1024 if which == "k1024" else 256)
+        bh, K = 4, {"k1024": 1024, "k4096": 4096}.get(which, 256)
         crop = bench.structured_image(2048, 2048, 0, dev)
     elif which == "iid":
         img = bench.iid_image(8192, 8192, 1, dev)
@@ -45,8 +45,9 @@ def setup(which):
         img = bench.structured_image(8192, 8192, 7, dev)
         bh, K = 8, 256
         crop = img[:2048, :2048].contiguous()
-    elif which == "cfg5":
-        img = bench.structured_image(4096, 4096, 5, dev, channels=3)
+    elif which in ("cfg5", "cfg5big"):
+        side = 8192 if which == "cfg5big" else 4096
+        img = bench.structured_image(side, side, 5, dev, channels=3)
         bh, K = 8, 4096
         crop = img[:1024, :1024].contiguous()
     else:

@@ -1835,6 +1835,8 @@ constexpr int tile_k_for(int dp2) { return dp2 <= 8 ? 128 : (dp2 <= 16 ? 64 : (d
 // the bound as the best distances improve.  Results are identical to the full search.
 #ifdef VQ_WAVES_PER_EU
 #define VQ_ASSIGN_ATTR __attribute__((amdgpu_waves_per_eu(VQ_WAVES_PER_EU, VQ_WAVES_PER_EU)))
+#elif defined(VQ_NUM_SGPR)
+#define VQ_ASSIGN_ATTR __attribute__((amdgpu_num_sgpr(VQ_NUM_SGPR)))
 #else
 #define VQ_ASSIGN_ATTR
 #endif
@@ -2235,37 +2237,51 @@ __global__ __launch_bounds__(ACC ? 1024 : 512) VQ_ASSIGN_ATTR void k_assign_fast
 #pragma unroll 2
                     for (int kk = 0; kk < TILE_K; ++kk) {
                         uint32_t cw[DP2];
+                        if constexpr (DP2 % 4 == 0) {              // rows of whole 16-byte pieces: ds_read_b128
+                            const uint4 *rowv = reinterpret_cast<const uint4 *>(cwbuf + kk * DP2);
 #pragma unroll
-                        for (int p = 0; p < DP2; ++p) cw[p] = cwbuf[kk * DP2 + p];
+                            for (int q = 0; q < DP2 / 4; ++q) {
+                                const uint4 v = rowv[q];
+                                cw[4 * q] = v.x;
+                                cw[4 * q + 1] = v.y;
+                                cw[4 * q + 2] = v.z;
+                                cw[4 * q + 3] = v.w;
+                            }
+                        } else {
+#pragma unroll
+                            for (int p = 0; p < DP2; ++p) cw[p] = cwbuf[kk * DP2 + p];
+                        }
                         step(cw, bbuf[kk], t * TILE_K + kk);
                     }
                 } else {
                     // long rows: read the row in chunks of CH words, one chunk ahead of the SADs that
                     // use it, so that only two chunks of the row are in registers at a time
+                    // (the rows start at multiples of 16 bytes -- DP2 and the tile are multiples of four words -- and are
+                    // read as 16-byte pieces: one ds_read_b128 moves in 4 LDS cycles what two ds_read2_b32 move in 8)
                     constexpr int CH = 8;
                     constexpr int NCH = DP2 / CH;
+                    static_assert(DP2 % CH == 0 && TILE_W % 4 == 0, "rows are whole 16-byte pieces");
                     for (int kk = 0; kk < TILE_K; ++kk) {
-                        const uint32_t *rowp = cwbuf + kk * DP2;
+                        const uint4 *rowv = reinterpret_cast<const uint4 *>(cwbuf + kk * DP2);
                         uint32_t acc[R];
 #pragma unroll
                         for (int r = 0; r < R; ++r) acc[r] = 0;
-                        uint32_t cur[CH], nxt[CH];
-#pragma unroll
-                        for (int p = 0; p < CH; ++p) cur[p] = rowp[p];
+                        uint4 cur0 = rowv[0], cur1 = rowv[1], nxt0 = cur0, nxt1 = cur1;
 #pragma unroll
                         for (int c = 0; c < NCH; ++c) {
                             if (c + 1 < NCH) {
-#pragma unroll
-                                for (int p = 0; p < CH; ++p) nxt[p] = rowp[(c + 1) * CH + p];
+                                nxt0 = rowv[2 * (c + 1)];
+                                nxt1 = rowv[2 * (c + 1) + 1];
                             }
+                            const uint32_t cur[CH] = {cur0.x, cur0.y, cur0.z, cur0.w, cur1.x, cur1.y, cur1.z, cur1.w};
 #pragma unroll
                             for (int r = 0; r < R; ++r) {
 #pragma unroll
                                 for (int p = 0; p < CH; ++p) acc[r] = __builtin_amdgcn_sad_u16(x[r][c * CH + p], cur[p], acc[r]);
                             }
                             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                            for (int p = 0; p < CH; ++p) cur[p] = nxt[p];
+                            cur0 = nxt0;
+                            cur1 = nxt1;
                         }
                         finish(acc, bbuf[kk], t * TILE_K + kk);
                     }
@@ -3765,6 +3781,12 @@ int launch_assign_fast_t(const AssignArgs &a, const uint32_t *c16, const uint32_
                                     (int)lds));
     const hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
     g_prof_start = g_prof_stop = nullptr;
+#ifdef VQ_DEBUG_LDS
+    if (PRUNE && !LDS_CW && !ACC && getenv("VQ_DEBUG_LDS")) {
+        lds = (size_t)atoi(getenv("VQ_DEBUG_LDS"));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+#endif
     if (ev0) HIP_TRY(hipEventRecord(ev0, st));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, st, a, c16, bias, a.cb);
     LAUNCH_CHECK("k_assign_fast");
