@@ -2411,11 +2411,29 @@ __global__ __launch_bounds__(ACC ? 1024 : 512) VQ_ASSIGN_ATTR void k_assign_fast
                             double acc = 0.0;
                             uint32_t sv = s;                   // opaque per trip: the element conversions stay inside
                             asm volatile("" : "+v"(sv));       // the loop (hoisted, they would hold 4 * DP2 registers)
+                            if (d == 2 * DP2) {
+                                // whole rows: no test between the elements, so the row arrives four elements per scalar
+                                // load instead of one memory round trip per element
+                                constexpr int CE = (2 * DP2) % 4 == 0 ? 4 : 2;
 #pragma unroll
-                            for (int e = 0; e < 2 * DP2; ++e) {
-                                if (e < d) {
-                                    const double xe = (double)((xw[e >> 1] >> (sv + 16 * (e & 1))) & 0xffu);
-                                    acc += fabs(xe - crow[e]);
+                                for (int e0 = 0; e0 < 2 * DP2; e0 += CE) {
+                                    double cv[CE];
+#pragma unroll
+                                    for (int i = 0; i < CE; ++i) cv[i] = crow[e0 + i];
+#pragma unroll
+                                    for (int i = 0; i < CE; ++i) {
+                                        const double xe = (double)((xw[(e0 + i) >> 1] >> (sv + 16 * (i & 1))) & 0xffu);
+                                        acc += fabs(xe - cv[i]);
+                                    }
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 2 * DP2; ++e) {
+                                    if (e < d) {
+                                        const double xe = (double)((xw[e >> 1] >> (sv + 16 * (e & 1))) & 0xffu);
+                                        acc += fabs(xe - crow[e]);
+                                    }
                                 }
                             }
                             if (acc < best || (acc == best && kk < bk)) {
@@ -2517,6 +2535,24 @@ __global__ __launch_bounds__(ACC ? 1024 : 512) VQ_ASSIGN_ATTR void k_assign_fast
             if (want_dist) {
                 double acc = 0.0;
                 auto measure = [&](const double *crow) {
+                    if (d == 2 * DP2) {
+                        // whole rows: four codeword elements are fetched at a time, ahead of the additions that use
+                        // them (a test per element would put a memory round trip between any two additions)
+                        constexpr int CE = (2 * DP2) % 4 == 0 ? 4 : 2;     // elements per batch
+#pragma unroll
+                        for (int e0 = 0; e0 < 2 * DP2; e0 += CE) {
+                            double cv[CE];
+#pragma unroll
+                            for (int i = 0; i < CE; ++i) cv[i] = crow[e0 + i];
+#pragma unroll
+                            for (int i = 0; i < CE; ++i) {
+                                const double xv = (double)((x[r][(e0 + i) >> 1] >> (s + 16 * (i & 1))) & 0xffu);
+                                acc += fabs(xv - cv[i]);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        return;
+                    }
 #pragma unroll
                     for (int p = 0; p < DP2; ++p) {
 #pragma unroll
