@@ -262,6 +262,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--lanes", type=int, default=6,
+                    help="HIP streams that consecutive steps alternate between (1 = every step on one stream)")
     ap.add_argument("--cpu-sample", type=int, default=1 << 22, help="block vectors timed on the host (0 = skip)")
     ap.add_argument("--no-shapes", action="store_true", help="skip the other-shape and full-training measurements")
     ap.add_argument("--cpu-baseline-file", default=None, help=argparse.SUPPRESS)
@@ -288,7 +290,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
         group = dist.group.WORLD
 
-    from vector_quantization_amd import HipEngine, train_lbg, lbg_iteration
+    from vector_quantization_amd import HipEngine, EncodePipeline, train_lbg, lbg_iteration
     from vector_quantization_amd import _lib
     from vector_quantization_amd.lbg import shards_chunk_aligned
     eng = HipEngine(device)
@@ -307,18 +309,22 @@ def main():
     labels = torch.empty(N, dtype=torch.int32, device=device)
     scratch = torch.empty(_lib.lib.vq_sorted_bytes(d, N), dtype=torch.uint8, device=device)
 
+    # A step: image -> sorted block vectors -> prepared codebook -> pruned search (near-ties re-checked in fp64 inside
+    # the same kernel) -> labels -> decoded image.  Consecutive steps go to different HIP streams (each lane with its own
+    # workspace, sorted buffer, labels and output), so that the byte-moving kernels of one step and the start of its
+    # search run in what the search of the step before leaves free; every step does all of its work inside the timed
+    # region, which ends with a device-wide synchronisation.
+    pipe = EncodePipeline(device, lanes=max(1, args.lanes))
+
     def step():
-        # image -> sorted block vectors -> prepared codebook -> pruned search (near-ties re-checked in fp64 inside
-        # the same kernel) -> decode
-        eng.encode_image(img, BH, BW, cb, scratch=scratch, labels=labels)
-        return eng.decode(labels.view(nr, nc), cb, BH, BW, 1)
+        return pipe.submit(img, BH, BW, cb, inputs_ready=True)    # (resident before the timed region starts)
 
     for _ in range(args.warmup):
         step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step()
+        last = step()
     barrier()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -326,7 +332,22 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(t.item())
     value = world * N * args.steps / elapsed
-    labels_step = labels.clone()
+    labels_step = last.labels.clone()
+
+    # the same steps one after the other on one stream (the latency of a step rather than the throughput of many)
+    def step_sequential():
+        eng.encode_image(img, BH, BW, cb, scratch=scratch, labels=labels)
+        return eng.decode(labels.view(nr, nc), cb, BH, BW, 1)
+
+    for _ in range(args.warmup):
+        step_sequential()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step_sequential()
+    barrier()
+    sequential_ms = (time.perf_counter() - t0) / args.steps * 1e3
+    sequential_labels_equal = bool(torch.equal(labels, labels_step))
 
     # ---- the kernels of the step on their own, HIP events on the launch stream ---------------------------
     reps = max(20, min(args.steps, 200))
@@ -473,6 +494,11 @@ def main():
         "config": {"workload": "configs[1]: synthetic 8192x8192 grayscale per GPU, 4x4 blocks (dim 16), K=256, "
                                "encode+decode starting from the image", "vectors_per_gpu": N, "K": K_CODEBOOK, "dim": d,
                    "parallelism": f"dp{world} (block vectors sharded by image, codebook replicated)"},
+        "step_issue": f"consecutive steps alternate between {max(1, args.lanes)} HIP streams (EncodePipeline); every step "
+                      "runs all of its kernels; one stream: sequential_ms_per_step",
+        "sequential_ms_per_step": sequential_ms,
+        "sequential_vectors_per_s_per_gpu": N / (sequential_ms * 1e-3),
+        "sequential_labels_equal": sequential_labels_equal,
         "encode_ms": enc_ms,
         "encode_vectors_per_s_per_gpu": N / (enc_ms * 1e-3),
         "decode_vectors_per_s_per_gpu": N / (dec_ms * 1e-3),

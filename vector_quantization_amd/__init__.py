@@ -9,10 +9,11 @@ from . import _lib  # noqa: F401  (loads and type-checks the C ABI; raises if th
 from .codebook import Codebook, validate_image_path
 from .engine import HipEngine
 from .gray import GrayCodebook
+from .pipeline import EncodePipeline
 from .lbg import train_lbg, lbg_iteration, initial_centroid, final_codebook_size, LBGResult
 from ._lib import VQ_MODE_EXACT, VQ_MODE_FAST, VQ_PAD_EDGE, VQ_PAD_ZERO
 
 __all__ = [
-    "Codebook", "GrayCodebook", "validate_image_path", "HipEngine", "train_lbg", "lbg_iteration", "initial_centroid",
+    "Codebook", "GrayCodebook", "validate_image_path", "HipEngine", "EncodePipeline", "train_lbg", "lbg_iteration", "initial_centroid",
     "final_codebook_size", "LBGResult", "VQ_MODE_EXACT", "VQ_MODE_FAST", "VQ_PAD_EDGE", "VQ_PAD_ZERO",
 ]

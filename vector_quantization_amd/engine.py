@@ -448,12 +448,16 @@ class HipEngine:
         return cb2
 
     # -- decode (VQ_Full.py:157-169) -------------------------------------------------------------------
-    def decode(self, labels, cb, bh, bw, C):
+    def decode(self, labels, cb, bh, bw, C, out=None):
         labels = self._dev(labels, torch.int32)
         nr, nc = labels.shape
         cb = self._dev(cb, torch.float64).reshape(-1, bh * bw * C)
         K = cb.shape[0]
-        img = torch.empty((nr * bh, nc * bw, C), dtype=torch.uint8, device=self.device)
+        shape = (nr * bh, nc * bw, C)
+        if out is not None and (tuple(out.shape) != shape or out.dtype != torch.uint8 or out.device != self.device or
+                                not out.is_contiguous()):
+            raise ValueError(f"out must be a contiguous uint8 tensor of shape {shape} on {self.device}")
+        img = out if out is not None else torch.empty(shape, dtype=torch.uint8, device=self.device)
         ws = self._workspace(K, bh * bw * C)
         with torch.cuda.device(self.device):
             check(lib.vq_decode_u8(_ptr(labels), nr, nc, _ptr(cb), K, bh, bw, C, _ptr(img), _ptr(ws), ws.numel(),
