@@ -33,7 +33,12 @@ def _structured(rng, K, d, N, noise=10.0):
 
 
 @pytest.mark.parametrize("shape,bh,bw,pad", [((33, 17, 1), 4, 4, 0), ((7, 5, 3), 2, 2, 1), ((64, 64, 1), 4, 4, 0),
-                                             ((52, 1040, 1), 4, 4, 0), ((1028, 528, 1), 4, 4, 1)])
+                                             ((52, 1040, 1), 4, 4, 0), ((1028, 528, 1), 4, 4, 1),
+                                             # row strips of up to 256 blocks (segments of whole words, 16-byte vectors):
+                                             # two strips per block row, rows that are not whole words, padding on
+                                             # both edges; 64-byte and 192-byte vectors
+                                             ((13, 1030, 3), 4, 4, 0), ((13, 1030, 3), 4, 4, 1), ((17, 520, 1), 8, 8, 0),
+                                             ((10, 515, 3), 8, 8, 1), ((9, 301, 4), 4, 1, 0)])
 def test_emu_blocks(eng, oracle, shape, bh, bw, pad):
     img = np.random.default_rng(1).integers(0, 256, size=shape, dtype=np.uint8)
     got = eng.blocks_from_image(T(img), bh, bw, pad).numpy()

@@ -35,7 +35,11 @@ def test_blocks_golden(eng, train_case):
 
 
 @pytest.mark.parametrize("shape,bh,bw", [((7, 5, 3), 2, 2), ((33, 17, 1), 4, 4), ((64, 64, 3), 8, 8), ((9, 9, 1), 3, 3),
-                                         ((5, 7, 3), 1, 1), ((16, 20, 2), 4, 2), ((3, 3, 1), 4, 4), ((130, 67, 3), 3, 5)])
+                                         ((5, 7, 3), 1, 1), ((16, 20, 2), 4, 2), ((3, 3, 1), 4, 4), ((130, 67, 3), 3, 5),
+                                         # row strips (segments of whole words, 16-byte vectors, at least 64 blocks per
+                                         # block row): several strips, unaligned rows, padding on both edges
+                                         ((37, 1030, 3), 4, 4), ((64, 4090, 3), 4, 4), ((33, 520, 1), 8, 8),
+                                         ((70, 515, 3), 8, 8), ((9, 301, 4), 4, 1), ((40, 2050, 1), 4, 4)])
 @pytest.mark.parametrize("pad_mode", [0, 1])
 def test_blocks_ragged(eng, oracle, shape, bh, bw, pad_mode):
     rng = np.random.default_rng(hash((shape, bh, bw)) & 0xffff)

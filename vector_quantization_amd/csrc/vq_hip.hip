@@ -458,6 +458,61 @@ __global__ __launch_bounds__(256) void k_blocks_u8(const uint8_t *__restrict__ i
     }
 }
 
+// Blocks whose row segments are whole words (bw * C % 4 == 0) and whose vectors are whole 16-byte pieces (d % 16 == 0,
+// d <= 192) -- RGB 4x4 and 8x8, gray 8x8: a workgroup takes up to 256 consecutive blocks of one block row.  For each of
+// their bh pixel rows it copies the contiguous stretch of the image row into LDS, a thread moving the bw * C bytes of
+// its block to the block's place there (adjacent lanes read adjacent segments, at whatever byte alignment the image
+// row has); then the vectors leave as one contiguous run of 16-byte stores.  No division per word, every image byte
+// read once, every store a full line.  Words that reach into the padding are assembled byte by byte.
+__global__ __launch_bounds__(256) void k_blocks_rows(const uint8_t *__restrict__ img, int H, int W, int C, int bh, int bw,
+                                                     int pad_zero, uint8_t *__restrict__ blocks, int nr, int nc) {
+    extern __shared__ __align__(16) uint32_t s_tile[];           // 256 * d / 4 words
+    constexpr int TB = 256;
+    const int seg = bw * C, segw = seg >> 2, dw = (bh * seg) >> 2;
+    const int64_t rowbytes = (int64_t)W * C;
+    const int tiles_per_row = (nc + TB - 1) / TB;
+    const int64_t ntiles = (int64_t)nr * tiles_per_row;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {    // (workgroup-uniform)
+        const int r = (int)(t / tiles_per_row);
+        const int q0 = (int)(t - (int64_t)r * tiles_per_row) * TB;
+        const int nb = nc - q0 < TB ? nc - q0 : TB;
+        const int qq = threadIdx.x;
+        if (qq < nb) {
+            const int64_t xb0 = (int64_t)(q0 + qq) * seg;         // first byte of the block's segment in an image row
+            for (int i = 0; i < bh; ++i) {
+                const int y = r * bh + i;
+                const uint8_t *src = img + (size_t)(y < H ? y : H - 1) * rowbytes;
+                const bool zero_row = pad_zero && y >= H;
+                uint32_t *dst = s_tile + qq * dw + i * segw;
+                for (int rem = 0; rem < segw; ++rem) {
+                    const int64_t xb = xb0 + 4 * rem;
+                    uint32_t v = 0;
+                    if (!zero_row) {
+                        if (xb + 4 <= rowbytes) {
+                            v = load_u32_any(src + xb);
+                        } else {
+#pragma unroll
+                            for (int b4 = 0; b4 < 4; ++b4) {
+                                const int j = (4 * rem + b4) / C, ch = (4 * rem + b4) - j * C;
+                                const int x = (q0 + qq) * bw + j;
+                                uint32_t b = src[(size_t)(x < W ? x : W - 1) * C + ch];
+                                if (pad_zero && x >= W) b = 0;
+                                v |= b << (8 * b4);
+                            }
+                        }
+                    }
+                    dst[rem] = v;
+                }
+            }
+        }
+        __syncthreads();
+        uint4 *out = reinterpret_cast<uint4 *>(blocks + ((size_t)r * nc + q0) * ((size_t)dw * 4));
+        const int n16 = nb * (dw >> 2);
+        for (int k = threadIdx.x; k < n16; k += 256) out[k] = reinterpret_cast<const uint4 *>(s_tile)[k];
+        __syncthreads();
+    }
+}
+
 // 4x4 blocks of one-byte pixels, no padding, image rows multiples of 16 aligned bytes: a thread reads four
 // horizontally adjacent blocks with four 16-byte loads (one per pixel row; a wave's loads are contiguous
 // runs of the four rows) and regroups the words into the four 16-byte vectors.  The vectors go through LDS so
@@ -4480,6 +4535,14 @@ int vq_blocks_u8(const uint8_t *img, int H, int W, int C, int bh, int bw, int pa
         (reinterpret_cast<uintptr_t>(img) & 15) == 0 && (int64_t)nr * nc < (1ll << 31)) {
         const int64_t quads = (int64_t)nr * nc / 4;
         hipLaunchKernelGGL(k_blocks_quads, dim3(grid_for(quads, 256, 16384)), dim3(256), 0, st, img, W, blocks, nc, quads);
+    } else if (seg4 && d % 16 == 0 && d <= 192 && nc >= 64 && (optr & 15) == 0) {     // (narrow images: too few blocks per strip)
+        const int64_t tiles = (int64_t)nr * ((nc + 255) / 256);
+        const size_t lds = (size_t)256 * (size_t)d;
+        if (lds > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_blocks_rows), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds));
+        hipLaunchKernelGGL(k_blocks_rows, dim3(grid_for(tiles, 1, 1 << 20)), dim3(256), lds, st, img, H, W, C, bh, bw, pz, blocks,
+                           nr, nc);
     } else if (seg4 && total % 16 == 0 && (optr & 15) == 0) {
         int64_t groups = total / 16;
         hipLaunchKernelGGL(k_blocks_u8<16>, dim3(grid_for(groups, 256, 16384)), dim3(256), 0, st, img, H, W, C, bh, bw, pz,
