@@ -3653,6 +3653,21 @@ __global__ __launch_bounds__(256) void k_cb_to_u8(const double *__restrict__ cb,
         out[i] = cast_u8(cb[i]);
 }
 
+// The truncated codebook of the decode kernels in LDS: converted from the fp64 codebook (cb non-null: small codebooks),
+// or copied from the uint8 table k_cb_to_u8 left in global memory (cb null: a workgroup then reads K * d bytes
+// instead of K * d doubles -- with many workgroups per launch the conversions were most of the time of a decode of
+// 1 M RGB 4x4 blocks).  cb8g is 16-byte aligned.
+__device__ __forceinline__ void stage_cb8(uint8_t *s_cb8, const double *cb, const uint8_t *cb8g, uint32_t n) {
+    if (cb) {
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s_cb8[i] = cast_u8(cb[i]);
+    } else {
+        const uint32_t n16 = n / 16;
+        for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x)
+            reinterpret_cast<uint4 *>(s_cb8)[i] = reinterpret_cast<const uint4 *>(cb8g)[i];
+        for (uint32_t i = n16 * 16 + threadIdx.x; i < n; i += blockDim.x) s_cb8[i] = cb8g[i];
+    }
+}
+
 // Byte-wise decode for block row segments that are not a whole number of aligned words: one thread per
 // output byte of an image row.  blockIdx.y strides over image rows, so all index arithmetic is 32-bit.
 // With LDS_CB each workgroup truncates the fp64 codebook into LDS once (K*d bytes) and gathers from
@@ -3668,7 +3683,7 @@ __global__ __launch_bounds__(256) void k_decode_u8(const int32_t *__restrict__ l
     const uint32_t rows = (uint32_t)nr * (uint32_t)bh;
     if (LDS_CB) {
         const uint32_t n = (uint32_t)K * d;
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s_cb8[i] = cast_u8(cb[i]);
+        stage_cb8(s_cb8, cb, cb8g, n);
         __syncthreads();
     }
     const uint8_t *cb8 = LDS_CB ? s_cb8 : cb8g;
@@ -3701,7 +3716,7 @@ __global__ __launch_bounds__(256) void k_decode_blockrows_u8(const int32_t *__re
     const uint32_t groups_per_row = rowbytes / G;
     if (LDS_CB) {
         const uint32_t n = (uint32_t)K * d;
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s_cb8[i] = cast_u8(cb[i]);
+        stage_cb8(s_cb8, cb, cb8g, n);
         __syncthreads();
     }
     const uint8_t *cb8 = LDS_CB ? s_cb8 : cb8g;
@@ -5154,9 +5169,13 @@ int vq_decode_u8(const int32_t *labels, int nr, int nc, const double *cb, int K,
         LAUNCH_CHECK("k_decode_quads");
         return VQ_OK;
     }
-    if (!lds_cb) {
+    // the general kernels run many workgroups: beyond a few thousand entries the codebook is truncated once, by its
+    // own launch, and the workgroups stage the uint8 table
+    const bool convert_once = !lds_cb || (n > 4096 && (reinterpret_cast<uintptr_t>(cb8) & 15) == 0);
+    if (convert_once) {
         hipLaunchKernelGGL(k_cb_to_u8, dim3(grid_for(n, 256, 4096)), dim3(256), 0, st, cb, n, cb8);
         LAUNCH_CHECK("k_cb_to_u8");
+        if (lds_cb) cb = nullptr;                              // (the kernels' signal to stage from cb8)
     }
     const uintptr_t iptr = reinterpret_cast<uintptr_t>(img);
     const bool seg4 = (bw * C) % 4 == 0;
