@@ -38,7 +38,11 @@ def _structured(rng, K, d, N, noise=10.0):
                                              # two strips per block row, rows that are not whole words, padding on
                                              # both edges; 64-byte and 192-byte vectors
                                              ((13, 1030, 3), 4, 4, 0), ((13, 1030, 3), 4, 4, 1), ((17, 520, 1), 8, 8, 0),
-                                             ((10, 515, 3), 8, 8, 1), ((9, 301, 4), 4, 1, 0)])
+                                             ((10, 515, 3), 8, 8, 1), ((9, 301, 4), 4, 1, 0),
+                                             # strips for segments that are not whole words: 2x2 gray and RGB, 3x3, 1x1 RGB,
+                                             # odd widths, more blocks per row than one strip holds
+                                             ((9, 300, 1), 2, 2, 0), ((11, 301, 1), 2, 2, 1), ((10, 201, 3), 2, 2, 0),
+                                             ((10, 211, 1), 3, 3, 1), ((5, 100, 3), 1, 1, 0), ((4, 9001, 1), 2, 2, 0)])
 def test_emu_blocks(eng, oracle, shape, bh, bw, pad):
     img = np.random.default_rng(1).integers(0, 256, size=shape, dtype=np.uint8)
     got = eng.blocks_from_image(T(img), bh, bw, pad).numpy()
@@ -172,7 +176,12 @@ def test_emu_codebook_class_reproduces_reference_golden(tmp_path):
 
 @pytest.mark.parametrize("K,bh,bw,C,nr,nc", [(256, 4, 4, 1, 16, 64), (17, 2, 2, 3, 5, 8), (33, 8, 8, 3, 3, 4), (9, 3, 3, 1, 4, 5),
                                              (4100, 4, 4, 1, 9, 300), (31, 4, 4, 1, 40, 1800), (12, 4, 2, 2, 7, 44),
-                                             (50, 4, 4, 1, 6, 30)])
+                                             (50, 4, 4, 1, 6, 30),
+                                             # strips of a block row through LDS (segments that are not whole words, at
+                                             # least 64 blocks per block row): one strip, several strips, codebook too
+                                             # large for LDS, three-byte and nine-byte vectors
+                                             (16, 2, 2, 1, 5, 150), (16, 2, 2, 1, 2, 4500), (7, 2, 2, 3, 4, 100),
+                                             (5, 3, 3, 1, 3, 70), (300, 1, 1, 3, 2, 100), (9000, 3, 3, 1, 2, 80)])
 def test_emu_decode_both_kernels(eng, oracle, K, bh, bw, C, nr, nc):
     """16-byte codewords of four 4-byte pixel rows take k_decode_quads (codebook in LDS or not, several trips),
     other word-wide block rows k_decode_blockrows_u8, the rest the byte-wise k_decode_u8."""

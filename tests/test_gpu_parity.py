@@ -39,7 +39,10 @@ def test_blocks_golden(eng, train_case):
                                          # row strips (segments of whole words, 16-byte vectors, at least 64 blocks per
                                          # block row): several strips, unaligned rows, padding on both edges
                                          ((37, 1030, 3), 4, 4), ((64, 4090, 3), 4, 4), ((33, 520, 1), 8, 8),
-                                         ((70, 515, 3), 8, 8), ((9, 301, 4), 4, 1), ((40, 2050, 1), 4, 4)])
+                                         ((70, 515, 3), 8, 8), ((9, 301, 4), 4, 1), ((40, 2050, 1), 4, 4),
+                                         # strips for segments that are not whole words
+                                         ((9, 300, 1), 2, 2), ((11, 301, 1), 2, 2), ((10, 201, 3), 2, 2), ((10, 211, 1), 3, 3),
+                                         ((5, 100, 3), 1, 1), ((4, 9001, 1), 2, 2), ((2049, 2051, 1), 2, 2), ((33, 1000, 3), 5, 3)])
 @pytest.mark.parametrize("pad_mode", [0, 1])
 def test_blocks_ragged(eng, oracle, shape, bh, bw, pad_mode):
     rng = np.random.default_rng(hash((shape, bh, bw)) & 0xffff)
@@ -467,6 +470,27 @@ def test_decode_golden(eng, train_case):
     C = g["img"].shape[2]
     img = eng.decode(dev(g["labels"], torch.int32), dev(g["codebook"]), int(g["bh"]), int(g["bw"]), C)
     assert np.array_equal(img.cpu().numpy(), g["decoded"])
+
+
+@pytest.mark.parametrize("K,bh,bw,C,nr,nc", [(16, 2, 2, 1, 5, 150), (16, 2, 2, 1, 3, 4500), (7, 2, 2, 3, 4, 100), (5, 3, 3, 1, 3, 70),
+                                             (300, 1, 1, 3, 2, 100), (9000, 3, 3, 1, 2, 80), (16, 2, 2, 1, 1025, 1026),
+                                             (256, 4, 4, 3, 9, 1023), (64, 8, 8, 1, 5, 65), (40, 5, 3, 3, 7, 333)])
+@pytest.mark.parametrize("offset", [0, 1, 2])
+def test_decode_shapes_and_alignments(eng, oracle, K, bh, bw, C, nr, nc, offset):
+    """Every decode kernel (quads, word-wide block rows, strips through LDS, byte-wise) on images that start at any byte
+    alignment, with more blocks per row than one strip holds and codebooks that do and do not fit the LDS."""
+    rng = np.random.default_rng(K * 31 + nr + nc)
+    cb = rng.random((K, bh * bw * C)) * 300.0 - 20.0
+    labels = rng.integers(0, K, size=(nr, nc)).astype(np.int32)
+    want = oracle.decode_u8(labels, cb, bh, bw, C)
+    shape = (nr * bh, nc * bw, C)
+    numel = shape[0] * shape[1] * shape[2]
+    buf = torch.full((numel + 64,), 0xAB, dtype=torch.uint8, device="cuda:0")
+    out = buf[16 + offset: 16 + offset + numel].view(shape)
+    got = eng.decode(dev(labels), dev(cb), bh, bw, C, out=out)
+    assert np.array_equal(got.cpu().numpy(), want)
+    guard = buf.cpu().numpy()
+    assert (guard[:16 + offset] == 0xAB).all() and (guard[16 + offset + numel:] == 0xAB).all()     # nothing written outside
 
 
 def test_decode_known_answer(eng):

@@ -513,6 +513,83 @@ __global__ __launch_bounds__(256) void k_blocks_rows(const uint8_t *__restrict__
     }
 }
 
+// Any block shape (segments that are not whole words: 2x2 and 3x3 blocks, RGB 2x2 ...): a workgroup takes a strip of
+// up to TB consecutive blocks of one block row.  Phase 1 copies the strip's stretch of each of its bh image rows into
+// LDS word by word (coalesced; at whatever byte alignment the image row has; words that reach past the row are
+// assembled byte by byte with the padding rule).  Phase 2: a thread per block collects the block's bytes from the LDS
+// rows and stores its vector -- as words when d is a multiple of four (adjacent lanes then write adjacent vectors).
+// rs: bytes per LDS row, a multiple of four, at least TB * seg.
+__global__ __launch_bounds__(256) void k_blocks_strip(const uint8_t *__restrict__ img, int H, int W, int C, int bh, int bw,
+                                                      int pad_zero, uint8_t *__restrict__ blocks, int nr, int nc, int TB, int rs,
+                                                      int word_stores) {
+    extern __shared__ __align__(16) uint32_t s_rows[];           // bh rows of rs bytes
+    const uint8_t *s_bytes = reinterpret_cast<const uint8_t *>(s_rows);
+    const int seg = bw * C, d = bh * seg;
+    const int64_t rowbytes = (int64_t)W * C;
+    const int tiles_per_row = (nc + TB - 1) / TB;
+    const int64_t ntiles = (int64_t)nr * tiles_per_row;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {    // (workgroup-uniform)
+        const int r = (int)(t / tiles_per_row);
+        const int q0 = (int)(t - (int64_t)r * tiles_per_row) * TB;
+        const int nb = nc - q0 < TB ? nc - q0 : TB;
+        const int64_t xb_start = (int64_t)q0 * seg;
+        const int nw = (nb * seg + 3) >> 2;
+        for (int i = 0; i < bh; ++i) {
+            const int y = r * bh + i;
+            const uint8_t *src = img + (size_t)(y < H ? y : H - 1) * rowbytes;
+            const bool zero_row = pad_zero && y >= H;
+            for (int w = threadIdx.x; w < nw; w += 256) {
+                const int64_t xb = xb_start + 4 * w;
+                uint32_t v = 0;
+                if (!zero_row) {
+                    if (xb + 4 <= rowbytes) {
+                        v = load_u32_any(src + xb);
+                    } else {
+#pragma unroll
+                        for (int b4 = 0; b4 < 4; ++b4) {
+                            const int64_t j = (xb + b4) / C;                 // pixel column of this byte
+                            const int ch = (int)((xb + b4) - j * C);
+                            uint32_t b = src[(size_t)(j < W ? j : W - 1) * C + ch];
+                            if (pad_zero && j >= W) b = 0;
+                            v |= b << (8 * b4);
+                        }
+                    }
+                }
+                s_rows[i * (rs >> 2) + w] = v;
+            }
+        }
+        __syncthreads();
+        for (int qq = threadIdx.x; qq < nb; qq += 256) {
+            uint8_t *out = blocks + ((size_t)r * nc + q0 + qq) * (size_t)d;
+            const uint8_t *col = s_bytes + qq * seg;
+            int i = 0, rem = 0;                                   // element e = i * seg + rem of the vector
+            if (word_stores) {
+                for (int e = 0; e < d; e += 4) {
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int b4 = 0; b4 < 4; ++b4) {
+                        v |= (uint32_t)col[i * rs + rem] << (8 * b4);
+                        if (++rem == seg) {
+                            rem = 0;
+                            ++i;
+                        }
+                    }
+                    *reinterpret_cast<uint32_t *>(out + e) = v;
+                }
+            } else {
+                for (int e = 0; e < d; ++e) {
+                    out[e] = col[i * rs + rem];
+                    if (++rem == seg) {
+                        rem = 0;
+                        ++i;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // 4x4 blocks of one-byte pixels, no padding, image rows multiples of 16 aligned bytes: a thread reads four
 // horizontally adjacent blocks with four 16-byte loads (one per pixel row; a wave's loads are contiguous
 // runs of the four rows) and regroups the words into the four 16-byte vectors.  The vectors go through LDS so
@@ -3698,6 +3775,63 @@ __global__ __launch_bounds__(256) void k_decode_u8(const int32_t *__restrict__ l
     }
 }
 
+// Decode for any block shape (segments that are not whole words, image rows at any alignment): a workgroup takes a
+// strip of up to TB consecutive blocks of one block row.  Phase 1: a thread per block copies its codeword's bytes
+// (truncated codebook in LDS when it fits) into bh LDS rows at the block's place -- each row shifted by the byte
+// alignment of its destination in the image, so that aligned words of the image are aligned words of LDS.  Phase 2
+// writes every row out: leading bytes up to the first aligned address, whole words, trailing bytes.
+// rs: bytes per LDS row, a multiple of four, at least TB * seg + 4.
+template <bool LDS_CB>
+__global__ __launch_bounds__(256) void k_decode_strip(const int32_t *__restrict__ labels, int nr, int nc,
+                                                      const double *__restrict__ cb, const uint8_t *__restrict__ cb8g, int K,
+                                                      int bh, int bw, int C, uint8_t *__restrict__ img, int TB, int rs) {
+    extern __shared__ __align__(16) uint8_t s_cb8[];             // [truncated codebook, rounded up to 16 bytes |] bh rows
+    const int seg = bw * C, d = bh * seg;
+    const uint32_t n = (uint32_t)K * (uint32_t)d;
+    uint8_t *s_rows = s_cb8 + (LDS_CB ? ((n + 15u) & ~15u) : 0u);
+    if (LDS_CB) {
+        stage_cb8(s_cb8, cb, cb8g, n);
+        __syncthreads();
+    }
+    const uint8_t *cb8 = LDS_CB ? s_cb8 : cb8g;
+    const size_t rowbytes = (size_t)nc * seg;
+    const int tiles_per_row = (nc + TB - 1) / TB;
+    const int64_t ntiles = (int64_t)nr * tiles_per_row;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {    // (workgroup-uniform)
+        const int r = (int)(t / tiles_per_row);
+        const int q0 = (int)(t - (int64_t)r * tiles_per_row) * TB;
+        const int nb = nc - q0 < TB ? nc - q0 : TB;
+        uint8_t *dst0 = img + (size_t)r * bh * rowbytes + (size_t)q0 * seg;     // the strip in the block row's first pixel row
+        for (int qq = threadIdx.x; qq < nb; qq += 256) {
+            const uint32_t k = min((uint32_t)labels[(size_t)r * nc + q0 + qq], (uint32_t)K - 1u);    // stays in bounds
+            const uint8_t *crow = cb8 + (size_t)k * d;
+            int e = 0;
+            for (int i = 0; i < bh; ++i) {
+                const uint32_t a = (uint32_t)(reinterpret_cast<uintptr_t>(dst0 + (size_t)i * rowbytes) & 3u);
+                uint8_t *row = s_rows + (size_t)i * rs + a + (size_t)qq * seg;
+                for (int rem = 0; rem < seg; ++rem) row[rem] = crow[e++];
+            }
+        }
+        __syncthreads();
+        const int nbytes = nb * seg;
+        for (int i = 0; i < bh; ++i) {
+            uint8_t *dst = dst0 + (size_t)i * rowbytes;
+            const uint32_t a = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u);
+            const uint8_t *srow = s_rows + (size_t)i * rs + a;    // byte k of the strip's row
+            int head = (int)((4u - a) & 3u);
+            if (head > nbytes) head = nbytes;
+            const int nwords = (nbytes - head) >> 2;
+            const int tail0 = head + 4 * nwords;
+            if ((int)threadIdx.x < head) dst[threadIdx.x] = srow[threadIdx.x];
+            const uint32_t *sw = reinterpret_cast<const uint32_t *>(srow + head);        // (4-byte aligned: a + head = 0 mod 4)
+            uint32_t *dw = reinterpret_cast<uint32_t *>(dst + head);
+            for (int w = threadIdx.x; w < nwords; w += 256) dw[w] = sw[w];
+            if ((int)threadIdx.x < nbytes - tail0) dst[tail0 + threadIdx.x] = srow[tail0 + threadIdx.x];
+        }
+        __syncthreads();
+    }
+}
+
 // Decode for block row segments that are whole aligned words.  One thread per G consecutive output bytes
 // of an image row (G = 16: four words gathered from the truncated codebook, one 16-byte store; G = 4: one
 // word); blockIdx.y strides over BLOCK rows: a thread fetches the labels its G bytes need once and writes
@@ -4558,6 +4692,16 @@ int vq_blocks_u8(const uint8_t *img, int H, int W, int C, int bh, int bw, int pa
                                         (int)lds));
         hipLaunchKernelGGL(k_blocks_rows, dim3(grid_for(tiles, 1, 1 << 20)), dim3(256), lds, st, img, H, W, C, bh, bw, pz, blocks,
                            nr, nc);
+    } else if (nc >= 64 && d <= 768) {
+        // strips of TB blocks: TB * d bytes of LDS (at most 48 KB), TB a multiple of 256 up to 4096
+        int TB = (int)((48 * 1024) / d) / 256 * 256;
+        if (TB > 4096) TB = 4096;
+        if (TB < 64) TB = 64;
+        const int rs = (TB * (bw * C) + 3) / 4 * 4;
+        const int64_t tiles = (int64_t)nr * ((nc + TB - 1) / TB);
+        const int word_stores = (d % 4 == 0 && (optr & 3) == 0) ? 1 : 0;
+        hipLaunchKernelGGL(k_blocks_strip, dim3(grid_for(tiles, 1, 1 << 20)), dim3(256), (size_t)bh * rs, st, img, H, W, C, bh, bw,
+                           pz, blocks, nr, nc, TB, rs, word_stores);
     } else if (seg4 && total % 16 == 0 && (optr & 15) == 0) {
         int64_t groups = total / 16;
         hipLaunchKernelGGL(k_blocks_u8<16>, dim3(grid_for(groups, 256, 16384)), dim3(256), 0, st, img, H, W, C, bh, bw, pz,
@@ -5180,6 +5324,31 @@ int vq_decode_u8(const int32_t *labels, int nr, int nc, const double *cb, int K,
     const uintptr_t iptr = reinterpret_cast<uintptr_t>(img);
     const bool seg4 = (bw * C) % 4 == 0;
     const int G = (seg4 && rowbytes % 16 == 0 && (iptr & 15) == 0) ? 16 : ((seg4 && (iptr & 3) == 0) ? 4 : 1);
+    if (G == 1 && nc >= 64 && d <= 768) {
+        // (the byte-wise kernel otherwise: one thread per output byte)
+        int TB = (int)((48 * 1024) / d) / 256 * 256;
+        if (TB > 4096) TB = 4096;
+        if (TB < 64) TB = 64;
+        const int rs = (TB * (bw * C) + 4 + 3) / 4 * 4;
+        const size_t lds_s = (size_t)bh * rs + (lds_cb ? lds : 0);
+        const int64_t tiles = (int64_t)nr * ((nc + TB - 1) / TB);
+        const int grid_s = grid_for(tiles, 1, di.cus * 8);
+        if (lds_cb) {
+            if (lds_s > 48 * 1024)
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_decode_strip<true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+            hipLaunchKernelGGL((k_decode_strip<true>), dim3(grid_s), dim3(256), lds_s, st, labels, nr, nc, cb, cb8, K, bh, bw, C,
+                               img, TB, rs);
+        } else {
+            if (lds_s > 48 * 1024)
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_decode_strip<false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+            hipLaunchKernelGGL((k_decode_strip<false>), dim3(grid_s), dim3(256), lds_s, st, labels, nr, nc, cb, cb8, K, bh, bw, C,
+                               img, TB, rs);
+        }
+        LAUNCH_CHECK("k_decode_strip");
+        return VQ_OK;
+    }
     // a fixed number of workgroups (each stages the codebook once) laid out as (x over a row, y over rows)
     const int64_t groups_per_row = rowbytes / G;
     int gx = grid_for(groups_per_row, 256, 64);
