@@ -1939,6 +1939,7 @@ struct AssignArgs {
     int64_t dist_sorted_end;    // PRUNE: the distances of the vectors at sorted positions below this go to min_dist at
                                 // their SORTED position (coalesced stores; the reader un-permutes), the others by origin
     int cb_lds;                 // ACC: 1 = the fp64 codebook is staged in LDS (rows of d + 1 doubles) for the winners' distances
+    int tab_reps;               // ACC: copies of the LDS table (a power of two; see the kernel)
     int persist_tiles;          // ACC: > 0 = resident workgroups; every XCD's waves share this many tiles of 64 * R vectors
     int first_rows, round_rows; // PRUNE, scalar-load codewords: rows of the first round / added per side and later round (multiples of 8)
     int heavy_first;            // PRUNE: 1 = tiles from the middle of the sort windows are dispatched first (few-round launches)
@@ -1965,6 +1966,15 @@ constexpr int tile_k_for(int dp2) { return dp2 <= 8 ? 128 : (dp2 <= 16 ? 64 : (d
 // ambiguity window can be neither the nearest nor a near-tie for any of them: the wave searches a
 // contiguous range of the sorted codebook around its own sum, widening it in steps and narrowing
 // the bound as the best distances improve.  Results are identical to the full search.
+// Whether the scalar loads of the 16-byte-row pruned search run one pair of rows ahead of the arithmetic (36 more scalar
+// registers).  VQ_PREFETCH_ACC=0 leaves the fused LBG kernel, which is short of scalar registers, without it.
+#ifndef VQ_PREFETCH_ACC
+#define VQ_PREFETCH_ACC 1
+#endif
+#define VQ_PREFETCH_IN(acc) (!(acc) || VQ_PREFETCH_ACC)
+// The fused LBG kernel runs two workgroups of 12 waves per compute unit: six waves per SIMD, i.e. at most 80 vector
+// registers (the register allocator otherwise stops at 82 and the second workgroup no longer fits).
+#define VQ_ACC_ATTR(acc) __attribute__((amdgpu_waves_per_eu((acc) ? 6 : 1, (acc) ? 6 : 8)))
 #ifdef VQ_WAVES_PER_EU
 #define VQ_ASSIGN_ATTR __attribute__((amdgpu_waves_per_eu(VQ_WAVES_PER_EU, VQ_WAVES_PER_EU)))
 #elif defined(VQ_NUM_SGPR)
@@ -1980,7 +1990,7 @@ constexpr int tile_k_for(int dp2) { return dp2 <= 8 ? 128 : (dp2 <= 16 ? 64 : (d
 // stages its 64 rows and labels in LDS and re-reads them transposed -- 64 / EPL vectors x EPL
 // elements per instruction -- so that one atomic instruction spreads over 16+ distinct addresses.
 template <int DP2, int R, int KEYMODE, bool LDS_CW, bool PRUNE, bool ACC = false>
-__global__ __launch_bounds__(ACC ? 1024 : 512) VQ_ASSIGN_ATTR void k_assign_fast(const AssignArgs a, const uint32_t *__restrict__ c16,
+__global__ __launch_bounds__(ACC ? 1024 : 512) VQ_ASSIGN_ATTR VQ_ACC_ATTR(ACC) void k_assign_fast(const AssignArgs a, const uint32_t *__restrict__ c16,
                                                      const uint32_t *__restrict__ bias,
                                                      const double *__restrict__ cbrows) {
     static_assert(!ACC || (PRUNE && DP2 <= 16), "the fused accumulation belongs to the pruned variant");
@@ -2004,16 +2014,21 @@ __global__ __launch_bounds__(ACC ? 1024 : 512) VQ_ASSIGN_ATTR void k_assign_fast
     constexpr bool RESOLVE = resolves_in_kernel(DP2, LDS_CW, PRUNE);
     // LDS table of the fused accumulation: K rows of TROW words -- EPL byte sums (those beyond d stay zero), the
     // member count, one pad word, so that element pairs sit on 8-byte boundaries; row K is a dummy (never flushed)
+    // The table exists in a.tab_reps copies (small codebooks): the vectors that one atomic instruction adds go to
+    // different copies, so that vectors with the same label -- most of a sorted wave when K is small -- do not queue
+    // up on one LDS address.
     constexpr int TROW = EPL + 2;
     const int tabn = K * TROW;
-    uint8_t *st_rows = reinterpret_cast<uint8_t *>(s_tab + ((tabn + TROW + 3) & ~3)) + (tid >> 6) * (WAVE * EPL + WAVE * 4);
+    const int rep_words = tabn + TROW;                         // one copy, dummy row included
+    const int tab_all = ACC ? a.tab_reps * rep_words : 0;
+    uint8_t *st_rows = reinterpret_cast<uint8_t *>(s_tab + ((tab_all + 3) & ~3)) + (tid >> 6) * (WAVE * EPL + WAVE * 4);
     int32_t *st_lbl = reinterpret_cast<int32_t *>(st_rows + WAVE * EPL);
     // ACC with a.cb_lds: the fp64 codebook behind the staging areas, rows padded to d + 1 doubles (lanes read the same
     // element of different rows: the odd stride spreads them over the banks)
-    double *s_cbl = reinterpret_cast<double *>(reinterpret_cast<uint8_t *>(s_tab + ((tabn + TROW + 3) & ~3)) +
+    double *s_cbl = reinterpret_cast<double *>(reinterpret_cast<uint8_t *>(s_tab + ((tab_all + 3) & ~3)) +
                                                (BLOCK >> 6) * (WAVE * EPL + WAVE * 4));
     if (ACC) {
-        for (int i = tid; i < tabn; i += BLOCK) s_tab[i] = 0u;
+        for (int i = tid; i < tab_all; i += BLOCK) s_tab[i] = 0u;
         if (a.cb_lds) {
             for (int i = tid; i < K * d; i += BLOCK) {
                 const int kk = i / d;
@@ -2217,7 +2232,7 @@ __global__ __launch_bounds__(ACC ? 1024 : 512) VQ_ASSIGN_ATTR void k_assign_fast
             // hence the explicit requests.
             auto run = [&](int lo, int hi) {
                 if (lo >= hi) return;                          // (wave-uniform)
-                if constexpr (DP2 == 8 && U == 2 && KEYMODE == KEY_PACKED) {
+                if constexpr (DP2 == 8 && U == 2 && KEYMODE == KEY_PACKED && VQ_PREFETCH_IN(ACC)) {
                     // two 32-byte rows are one 64-byte scalar load, their biases one 8-byte load (lo is even)
                     u32x16 cur;
                     u32x2 cb2;
@@ -2638,7 +2653,9 @@ __global__ __launch_bounds__(ACC ? 1024 : 512) VQ_ASSIGN_ATTR void k_assign_fast
                     const uint32_t w = __builtin_amdgcn_perm(x[r][p + 1] >> s, x[r][p] >> s, 0x06040200u);
                     *reinterpret_cast<uint32_t *>(st_rows + lane * EPL + 2 * p) = w;
                 }
-                st_lbl[lane] = (settled ? idx : K) * TROW * 4;
+                // (the copy of the table this vector goes to: its slot within the instruction that adds it)
+                const int my_row = ((lane & (a.tab_reps - 1)) * (K + 1) + (settled ? idx : K)) * TROW;
+                st_lbl[lane] = my_row * 4;
                 // the staging area belongs to this wave alone and a wave's LDS operations complete in order:
                 // only the compiler has to be kept from moving them (a fence would also wait for the
                 // global stores in flight)
@@ -2659,7 +2676,7 @@ __global__ __launch_bounds__(ACC ? 1024 : 512) VQ_ASSIGN_ATTR void k_assign_fast
                     const unsigned long long v = (unsigned long long)(two & 0xffu) | ((unsigned long long)(two >> 8) << 32);
                     if (on) atomicAdd(reinterpret_cast<unsigned long long *>(tab_p + off), v);
                 }
-                atomicAdd(&s_tab[(settled ? idx : K) * TROW + EPL], 1u);
+                atomicAdd(&s_tab[my_row + EPL], 1u);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging area is rewritten by the next group
             }
             if (!settled) continue;
@@ -2750,7 +2767,8 @@ __global__ __launch_bounds__(ACC ? 1024 : 512) VQ_ASSIGN_ATTR void k_assign_fast
         __syncthreads();
         unsigned long long *rep = a.acc_rep + (size_t)(blockIdx.x % NREP) * (K * (d + 1));
         for (int i = tid; i < tabn; i += BLOCK) {
-            const uint32_t v = s_tab[i];
+            uint32_t v = 0;
+            for (int c = 0; c < a.tab_reps; ++c) v += s_tab[c * rep_words + i];
             const int kk = i / TROW, e = i - kk * TROW;            // replica rows are [d sums | count]
             if (v && (e < d || e == EPL)) atomicAdd(&rep[kk * (d + 1) + (e < d ? e : d)], (unsigned long long)v);
         }
@@ -3635,32 +3653,40 @@ __global__ __launch_bounds__(256) void k_accum_rows(const uint8_t *__restrict__ 
 // evaluates sum_e |x_e - cb[label][e]| in sequential fp64 (the value VQ_Full.py:89 gathers) for
 // every vector; CB_LDS stages the fp64 codebook in LDS behind the table.  VEC16: 16-byte rows.
 template <bool VEC16, bool CB_LDS>
-__global__ __launch_bounds__(512) void k_accum_dist(const uint8_t *__restrict__ blocks,
+__global__ __launch_bounds__(1024) void k_accum_dist(const uint8_t *__restrict__ blocks,
                                                     const uint16_t *__restrict__ perm, int64_t N, int d,
                                                     const int32_t *__restrict__ labels,
                                                     const double *__restrict__ cb, int K,
                                                     unsigned long long *__restrict__ sums,
                                                     unsigned long long *__restrict__ counts,
-                                                    double *__restrict__ min_dist, Gate gate) {
+                                                    double *__restrict__ min_dist, int reps, Gate gate) {
     extern __shared__ __align__(16) uint32_t s_acc[];
     if (gate_closed(gate)) return;
     const int tid = threadIdx.x;
+    // `reps` copies of the table (a power of two; more than one for small K): lane l adds to copy l mod reps, so that
+    // the lanes of a wave that hold the same label -- most of them when there are only a few labels -- do not all
+    // queue up on one LDS address
     const int tabn = K * (d + 1);
-    const double *s_cb = reinterpret_cast<const double *>(s_acc + ((tabn + 3) & ~3));
-    for (int i = tid; i < tabn; i += blockDim.x) s_acc[i] = 0u;
+    const int taball = reps * tabn;
+    const double *s_cb = reinterpret_cast<const double *>(s_acc + ((taball + 3) & ~3));
+    for (int i = tid; i < taball; i += blockDim.x) s_acc[i] = 0u;
     if (CB_LDS) {
-        double *dst = reinterpret_cast<double *>(s_acc + ((tabn + 3) & ~3));
+        double *dst = reinterpret_cast<double *>(s_acc + ((taball + 3) & ~3));
         for (int i = tid; i < K * d; i += blockDim.x) dst[i] = cb[i];
     }
     __syncthreads();
+    uint32_t *my_tab = s_acc + (size_t)(tid & (reps - 1)) * tabn;
     auto flush = [&]() {
         for (int i = tid; i < tabn; i += blockDim.x) {
-            const uint32_t v = s_acc[i];
+            uint32_t v = 0;
+            for (int r = 0; r < reps; ++r) {
+                v += s_acc[r * tabn + i];
+                s_acc[r * tabn + i] = 0u;
+            }
             if (v) {
                 const int kk = i / (d + 1), e = i - kk * (d + 1);
                 if (e < d) atomicAdd(&sums[(size_t)kk * d + e], (unsigned long long)v);
                 else atomicAdd(&counts[kk], (unsigned long long)v);
-                s_acc[i] = 0u;
             }
         }
     };
@@ -3689,7 +3715,7 @@ __global__ __launch_bounds__(512) void k_accum_dist(const uint8_t *__restrict__ 
 #pragma unroll
         for (int u = 0; u < UV; ++u) {
             if (n[u] >= N || (unsigned)k[u] >= (unsigned)K) continue;
-            uint32_t *t = s_acc + (size_t)k[u] * (d + 1);
+            uint32_t *t = my_tab + (size_t)k[u] * (d + 1);
             const double *crow = CB_LDS ? s_cb + (size_t)k[u] * d : cb + (size_t)k[u] * d;
             double acc = 0.0;
             if (VEC16) {
@@ -4296,15 +4322,17 @@ bool prune_supported(int K, int d) {
 // FAST mode on a prepared workspace: the filter kernel, then the fp64 fix-up of the vectors it
 // queued.  Writes labels and, when min_dist is non-null, the winning fp64 distances.
 // LDS bytes of the fused accumulation (table + per-wave staging) for a 256-thread workgroup.
-size_t fused_acc_lds(int K, int d, int waves = 4) {
+size_t fused_acc_lds(int K, int d, int waves = 4, int reps = 1) {
     const int dp2 = dp2_bucket(d);
-    return ((size_t)(K + 1) * (2 * dp2 + 2) + 3) / 4 * 16 + (size_t)waves * (WAVE * 2 * dp2 + WAVE * 4);
+    return ((size_t)reps * (K + 1) * (2 * dp2 + 2) + 3) / 4 * 16 + (size_t)waves * (WAVE * 2 * dp2 + WAVE * 4);
 }
 // The fused pass with the fp64 codebook in LDS as well: workgroups of VQ_ACC_WAVES waves, two of them per compute unit.
 #ifndef VQ_ACC_WAVES
 #define VQ_ACC_WAVES 12
 #endif
-size_t fused_acc_cb_lds(int K, int d) { return fused_acc_lds(K, d, VQ_ACC_WAVES) + (size_t)K * (d + 1) * 8; }
+size_t fused_acc_cb_lds(int K, int d, int reps = 1) {
+    return fused_acc_lds(K, d, VQ_ACC_WAVES, reps) + (size_t)K * (d + 1) * 8;
+}
 
 // Whether run_fast can accumulate sums / counts itself (pruned kernel, table within a quarter of the LDS).
 bool fused_acc_supported(const void *sorted, int K, int d) {
@@ -4362,8 +4390,16 @@ int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int
 #endif
     if (sums && !fused_acc_supported(sorted, K, d)) return fail(VQ_E_HIP, "internal: fused accumulation is not available here");
     // LDS-staged codewords: two tiles of rows and biases, plus the words of the workgroup reductions
+    // copies of the accumulation table: up to the number of vectors one atomic instruction adds, within the LDS budget
+    int tab_reps = 1;
+    if (sums) {
+        const int vs = WAVE / dp2;
+        while (2 * tab_reps <= vs && 2 * tab_reps <= 8 &&
+               (acc_cb_lds ? fused_acc_cb_lds(K, d, 2 * tab_reps) <= 80 * 1024 : fused_acc_lds(K, d, 4, 2 * tab_reps) <= 40 * 1024))
+            tab_reps *= 2;
+    }
     const size_t lds = lds_cw ? (size_t)2 * tile_k_for(dp2) * (dp2 + 1) * 4 + 128
-                              : (sums ? (acc_cb_lds ? fused_acc_cb_lds(K, d) : fused_acc_lds(K, d)) : 0);
+                              : (sums ? (acc_cb_lds ? fused_acc_cb_lds(K, d, tab_reps) : fused_acc_lds(K, d, 4, tab_reps)) : 0);
     const int64_t tile = (int64_t)block * R;
     const int64_t ntiles = (N + tile - 1) / tile;
     // One tile per workgroup: the dispatcher balances the chip and the last, partly filled round of
@@ -4387,6 +4423,7 @@ int run_fast(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int
     a.rows = nullptr; a.perm = nullptr; a.shdr = nullptr;
     a.dist_sorted_end = (prune && dist_sorted) ? N / NP_CHUNK * NP_CHUNK : 0;
     a.cb_lds = acc_cb_lds ? 1 : 0;
+    a.tab_reps = tab_reps;
     // Every round ends with a reduction over the wave and two table look-ups: larger steps mean fewer rounds and a few
     // rows searched for nothing.  Measured best: 32 rows first and per side for codebooks up to 512 rows, 64 per side
     // beyond (K = 1024, d = 16: 345 -> 323 us for 4.19 M vectors).
@@ -4498,14 +4535,22 @@ int run_accum(const uint8_t *blocks, const uint16_t *perm, int64_t N, int d, con
     int rc = device_info(di);
     if (rc) return rc;
     if (accum_table_fits(K, d, di)) {
-        const size_t tab = ((size_t)K * (d + 1) + 3) / 4 * 16;
+        // small codebooks: several copies of the table (see the kernel), as many as keep it within 16 KB, up to 32
+        int reps = 1;
+        while (reps < 32 && reps * K < 64 && (size_t)(2 * reps) * K * (d + 1) * 4 <= 16 * 1024) reps *= 2;
+        const size_t tab = ((size_t)reps * K * (d + 1) + 3) / 4 * 16;
         const size_t cbb = (size_t)K * d * 8;
         const bool cb_lds = min_dist != nullptr && tab + cbb <= 64 * 1024;
         const size_t lds = tab + (cb_lds ? cbb : 0);
         int wg_per_cu = (int)((160 * 1024) / (lds > 0 ? lds : 1));
         if (wg_per_cu > 4) wg_per_cu = 4;
         if (wg_per_cu < 1) wg_per_cu = 1;
-        constexpr int ACC_BLOCK = 512;
+        // large tables allow two workgroups per compute unit: with 1024 threads each they still fill its wave slots (the
+        // kernel waits on chains of dependent loads: label, then codebook row)
+#ifndef VQ_ACC_BLOCK_BIG
+#define VQ_ACC_BLOCK_BIG 1024
+#endif
+        const int ACC_BLOCK = wg_per_cu <= 2 ? VQ_ACC_BLOCK_BIG : 512;
         const int grid = grid_for(N, ACC_BLOCK, di.cus * wg_per_cu);
         const bool vec16 = d == 16 && (reinterpret_cast<uintptr_t>(blocks) & 15) == 0;
 #define VQ_LAUNCH_ACCUM(V, C)                                                                                          \
@@ -4514,7 +4559,7 @@ int run_accum(const uint8_t *blocks, const uint16_t *perm, int64_t N, int d, con
         if (lds > 48 * 1024)                                                                                           \
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                          \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(ACC_BLOCK), lds, st, blocks, perm, N, d, labels, cb, K, sums, counts, min_dist, g_gate); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(ACC_BLOCK), lds, st, blocks, perm, N, d, labels, cb, K, sums, counts, min_dist, reps, g_gate); \
     } while (0)
         if (vec16 && cb_lds) VQ_LAUNCH_ACCUM(true, true);
         else if (vec16) VQ_LAUNCH_ACCUM(true, false);
