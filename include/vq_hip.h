@@ -191,7 +191,9 @@ int vq_lbg_accum(const uint8_t *blocks, const void *sorted, size_t sorted_bytes,
  * host thread with the same ws, state, N, K and d, and no other entry point given that ws by that thread in between,
  * skip re-zeroing the tables of ws (the previous iteration leaves them zeroed); any other call sequence of that
  * thread costs one extra fill.  The note is per host thread: a workspace must not be shared between host threads,
- * nor written by the caller, while a stage runs. */
+ * nor written by the caller, while a stage runs.  labels and min_dist are scratch of the iteration: what they hold
+ * afterwards is unspecified (with a `sorted` buffer they stay in the order of the sorted vectors); use vq_encode_l1 /
+ * vq_lbg_accum for labels and distances in the caller's order. */
 /* 1 when vq_lbg_iterate in VQ_MODE_FAST with a `sorted` buffer runs this (K, d) as one fused pass (search and
  * accumulation in one kernel): labels may then be null (none are written, which saves their stores during
  * training) and min_dist is scratch whose contents are unspecified afterwards.  0: labels is required. */

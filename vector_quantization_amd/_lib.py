@@ -20,7 +20,7 @@ VQ_MODE_FAST = 1
 VQ_PAD_EDGE = 0
 VQ_PAD_ZERO = 1
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int

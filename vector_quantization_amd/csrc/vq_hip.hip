@@ -84,7 +84,7 @@ int fail(int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(VQ_E_HIP, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
     } while (0)
 
-constexpr int ABI_VERSION = 7;
+constexpr int ABI_VERSION = 8;
 constexpr int WAVE = 64;
 constexpr int64_t NP_CHUNK = 8192;      // numpy's reduction buffer: elements per pairwise-summed chunk
 constexpr int MAX_D_FAST = 192;         // largest vector dimension of the SAD filter kernels
@@ -2093,7 +2093,7 @@ __global__ __launch_bounds__(ACC ? 1024 : 512) VQ_ASSIGN_ATTR VQ_ACC_ATTR(ACC) v
             // (the fused LBG pass of a training run writes no labels and leaves its distances in sorted order: it
             // has no use for the origin map, except in the partial last chunk)
             origin[r] = 0u;
-            if (PRUNE && (!ACC || a.labels != nullptr || base + wave_off + WAVE * R > a.dist_sorted_end))
+            if (PRUNE && (base + wave_off + WAVE * R > a.dist_sorted_end))
                 origin[r] = (uint32_t)a.perm[n];
             // Out-of-row positions (d below the template's padded size) are loaded from a clamped
             // index and zeroed later, so that no load sits behind a branch.
@@ -2680,7 +2680,9 @@ __global__ __launch_bounds__(ACC ? 1024 : 512) VQ_ASSIGN_ATTR VQ_ACC_ATTR(ACC) v
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging area is rewritten by the next group
             }
             if (!settled) continue;
-            if (a.labels) a.labels[n] = idx;                   // (null: the fused LBG pass of a training run)
+            // (null: the fused LBG pass of a training run; whole chunks of a training pass: in sorted order, like
+            // the distances -- full-width stores instead of a scatter through the origin map)
+            if (a.labels) a.labels[PRUNE && ns < a.dist_sorted_end ? ns : n] = idx;
             if (want_dist) {
                 double acc = 0.0;
                 auto measure = [&](const double *crow) {
@@ -3659,7 +3661,9 @@ __global__ __launch_bounds__(1024) void k_accum_dist(const uint8_t *__restrict__
                                                     const double *__restrict__ cb, int K,
                                                     unsigned long long *__restrict__ sums,
                                                     unsigned long long *__restrict__ counts,
-                                                    double *__restrict__ min_dist, int reps, Gate gate) {
+                                                    double *__restrict__ min_dist, int reps, int64_t sorted_end, Gate gate) {
+    // sorted_end (with perm): labels and min_dist of the rows below it are indexed by the row's own (sorted) position,
+    // not through the origin map -- what the search of a training pass leaves
     extern __shared__ __align__(16) uint32_t s_acc[];
     if (gate_closed(gate)) return;
     const int tid = threadIdx.x;
@@ -3704,7 +3708,7 @@ __global__ __launch_bounds__(1024) void k_accum_dist(const uint8_t *__restrict__
             n[u] = n0 + u * stride + tid;
             const int64_t nc = n[u] < N ? n[u] : N - 1;           // clamped: loads stay in bounds
             m[u] = nc;
-            if (perm) {                                           // `blocks` is the sorted copy
+            if (perm && nc >= sorted_end) {                       // `blocks` is the sorted copy
                 m[u] = (nc & ~(int64_t)(SORT_WIN - 1)) + (int64_t)perm[nc];
                 m[u] = m[u] < N ? m[u] : N - 1;
             }
@@ -4530,7 +4534,8 @@ bool accum_table_fits(int K, int d, const DeviceInfo &di) { return (size_t)K * (
 // vector to its codeword: the LDS-table kernel when the table fits, else coalesced global atomics.
 // When the table does not fit, distances are NOT computed here (the caller asks the search for them).
 int run_accum(const uint8_t *blocks, const uint16_t *perm, int64_t N, int d, const int32_t *labels, const double *cb,
-              int K, unsigned long long *sums, unsigned long long *counts, double *min_dist, hipStream_t st) {
+              int K, unsigned long long *sums, unsigned long long *counts, double *min_dist, hipStream_t st,
+              int64_t sorted_end = 0) {
     DeviceInfo di;
     int rc = device_info(di);
     if (rc) return rc;
@@ -4559,7 +4564,7 @@ int run_accum(const uint8_t *blocks, const uint16_t *perm, int64_t N, int d, con
         if (lds > 48 * 1024)                                                                                           \
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                          \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(ACC_BLOCK), lds, st, blocks, perm, N, d, labels, cb, K, sums, counts, min_dist, reps, g_gate); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(ACC_BLOCK), lds, st, blocks, perm, N, d, labels, cb, K, sums, counts, min_dist, reps, sorted_end, g_gate); \
     } while (0)
         if (vec16 && cb_lds) VQ_LAUNCH_ACCUM(true, true);
         else if (vec16) VQ_LAUNCH_ACCUM(true, false);
@@ -4569,6 +4574,7 @@ int run_accum(const uint8_t *blocks, const uint16_t *perm, int64_t N, int d, con
         LAUNCH_CHECK("k_accum_dist");
         return VQ_OK;
     }
+    if (sorted_end != 0) return fail(VQ_E_HIP, "internal: sorted-order labels need the LDS-table accumulation");
     const int V = d >= WAVE ? 1 : WAVE / d;
     hipLaunchKernelGGL(k_accum_rows, dim3(grid_for((N + V - 1) / V, 4, 16384)), dim3(256), 0, st, blocks, perm, N, d, labels,
                        K, sums, counts, g_gate);
@@ -4586,6 +4592,33 @@ int run_numpy_sum(const double *v, int64_t N, double *chunk_sums, double *out, h
         int grid = grid_for(nfull, 1, di.cus * 8);
         hipLaunchKernelGGL(k_npsum_chunks, dim3(grid), dim3(512), 0, st, v, nfull, chunk_sums);
         LAUNCH_CHECK("k_npsum_chunks");
+    }
+    hipLaunchKernelGGL(k_npsum_final, dim3(1), dim3(1024), 0, st, v, N, nfull, chunk_sums, out);
+    LAUNCH_CHECK("k_npsum_final");
+    return VQ_OK;
+}
+
+// The same for distances whose whole chunks lie in the order of the window-sorted vectors: every chunk is put back into
+// the caller's order in LDS before it is summed (perm: the origin map of the sorted copy).
+__global__ __launch_bounds__(512) void k_npsum_chunks_sorted(const double *__restrict__ v, const uint16_t *__restrict__ perm,
+                                                             int64_t nfull, double *__restrict__ chunk_sums, Gate g) {
+    extern __shared__ __align__(16) double s_dist[];
+    __shared__ double s_leaf[64];
+    if (gate_closed(g)) return;
+    for (int64_t c = blockIdx.x; c < nfull; c += gridDim.x) npsum_chunk_sorted(v, perm, c, chunk_sums, s_leaf, s_dist);
+}
+int run_numpy_sum_sorted(const double *v, const uint16_t *perm, int64_t N, double *chunk_sums, double *out, hipStream_t st) {
+    const int64_t nfull = N / NP_CHUNK;
+    if (nfull > 0) {
+        DeviceInfo di;
+        int rc = device_info(di);
+        if (rc) return rc;
+        const size_t lds = (size_t)NP_CHUNK * sizeof(double);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_npsum_chunks_sorted),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_npsum_chunks_sorted, dim3(grid_for(nfull, 1, di.cus * 2)), dim3(512), lds, st, v, perm, nfull,
+                           chunk_sums, g_gate);
+        LAUNCH_CHECK("k_npsum_chunks_sorted");
     }
     hipLaunchKernelGGL(k_npsum_final, dim3(1), dim3(1024), 0, st, v, N, nfull, chunk_sums, out);
     LAUNCH_CHECK("k_npsum_final");
@@ -4979,9 +5012,31 @@ int vq_numpy_sum_f64(const double *v, int64_t N, double *out, double *chunk_sums
     return run_numpy_sum(v, N, chunk_sums, out, static_cast<hipStream_t>(stream));
 }
 
+}  // extern "C"
+namespace {
+int lbg_accum_impl(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d, const double *cb,
+                   int K, uint64_t *sums, uint64_t *counts, int32_t *labels, double *min_dist, double *dist_sum,
+                   double *chunk_sums, int mode, void *ws, size_t ws_bytes, void *stream, bool scratch_outputs);
+}
+extern "C" {
+
 int vq_lbg_accum(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d, const double *cb,
                  int K, uint64_t *sums, uint64_t *counts, int32_t *labels, double *min_dist, double *dist_sum,
                  double *chunk_sums, int mode, void *ws, size_t ws_bytes, void *stream) {
+    return lbg_accum_impl(blocks, sorted, sorted_bytes, N, d, cb, K, sums, counts, labels, min_dist, dist_sum, chunk_sums, mode,
+                          ws, ws_bytes, stream, false);
+}
+
+}  // extern "C"
+
+namespace {
+// scratch_outputs: labels and min_dist are scratch of a training iteration (nobody reads them afterwards): where the
+// search settles its near-ties itself and the accumulation runs through the LDS table, both stay in the order of the
+// sorted vectors -- full-width stores and loads instead of a scatter and a gather through the origin map, which across
+// the eight L2s cost several times their bytes in HBM traffic.
+int lbg_accum_impl(const uint8_t *blocks, const void *sorted, size_t sorted_bytes, int64_t N, int d, const double *cb,
+                   int K, uint64_t *sums, uint64_t *counts, int32_t *labels, double *min_dist, double *dist_sum,
+                   double *chunk_sums, int mode, void *ws, size_t ws_bytes, void *stream, bool scratch_outputs) {
     const bool via_sorted = sorted != nullptr && mode == VQ_MODE_FAST && K > 0 && d > 0 && prune_supported(K, d);
     int rc = check_common(blocks, N, d, cb, K, via_sorted);
     if (rc) return rc;
@@ -4994,6 +5049,8 @@ int vq_lbg_accum(const uint8_t *blocks, const void *sorted, size_t sorted_bytes,
     hipStream_t st = static_cast<hipStream_t>(stream);
     unsigned long long *s64 = reinterpret_cast<unsigned long long *>(sums);
     unsigned long long *c64 = reinterpret_cast<unsigned long long *>(counts);
+    bool sorted_io = false;
+    const uint16_t *sorted_perm = nullptr;
     if (N > 0) {
         DeviceInfo di;
         rc = device_info(di);
@@ -5007,8 +5064,11 @@ int vq_lbg_accum(const uint8_t *blocks, const void *sorted, size_t sorted_bytes,
                 rc = run_fast(blocks, sorted, sorted_bytes, N, d, cb, K, labels, min_dist, s64, c64, ws, st);
                 if (rc) return rc;
             } else {
+                const int dp2 = dp2_bucket(d);
+                sorted_io = scratch_outputs && via_sorted && dist_in_accum &&
+                            resolves_in_kernel(dp2, !prune_by_scalar_loads(K, dp2), true);
                 rc = run_fast(blocks, sorted, sorted_bytes, N, d, cb, K, labels, dist_in_accum ? nullptr : min_dist,
-                              nullptr, nullptr, ws, st);
+                              nullptr, nullptr, ws, st, 3, sorted_io);
                 if (rc) return rc;
                 // the accumulation pass takes the rows from the sorted copy when the search did
                 const uint8_t *acc_rows = blocks;
@@ -5018,8 +5078,10 @@ int vq_lbg_accum(const uint8_t *blocks, const void *sorted, size_t sorted_bytes,
                     acc_rows = reinterpret_cast<const uint8_t *>(static_cast<const char *>(sorted) + SL.rows);
                     acc_perm = reinterpret_cast<const uint16_t *>(static_cast<const char *>(sorted) + SL.perm);
                 }
-                rc = run_accum(acc_rows, acc_perm, N, d, labels, cb, K, s64, c64, dist_in_accum ? min_dist : nullptr, st);
+                rc = run_accum(acc_rows, acc_perm, N, d, labels, cb, K, s64, c64, dist_in_accum ? min_dist : nullptr, st,
+                               sorted_io ? N / NP_CHUNK * NP_CHUNK : 0);
                 if (rc) return rc;
+                sorted_perm = acc_perm;
             }
         } else {
             int grid = grid_for(N, 256, 16384);
@@ -5031,8 +5093,12 @@ int vq_lbg_accum(const uint8_t *blocks, const void *sorted, size_t sorted_bytes,
     }
     double *cs = chunk_sums ? chunk_sums
                             : reinterpret_cast<double *>(static_cast<char *>(ws) + ws_layout(K, d, N).chunks);
+    if (sorted_io) return run_numpy_sum_sorted(min_dist, sorted_perm, N, cs, dist_sum, st);
     return run_numpy_sum(min_dist, N, cs, dist_sum, st);
 }
+}  // namespace
+
+extern "C" {
 
 int vq_lbg_pass_fused(int K, int d) {
     static const char dummy = 0;                               // (any non-null `sorted`: only the shape decides)
@@ -5189,8 +5255,8 @@ int lbg_iterate_impl(const uint8_t *blocks, const void *sorted, size_t sorted_by
             HIP_TRY(hipMemsetAsync(counts, 0, bytes[1], st));
         }
     }
-    rc = vq_lbg_accum(blocks, sorted, sorted_bytes, N, d, cb, K, sums, counts, labels, min_dist,
-                      (finish || !total_out) ? &S->dist_sum : total_out, chunk_out, mode, ws, ws_bytes, stream);
+    rc = lbg_accum_impl(blocks, sorted, sorted_bytes, N, d, cb, K, sums, counts, labels, min_dist,
+                        (finish || !total_out) ? &S->dist_sum : total_out, chunk_out, mode, ws, ws_bytes, stream, true);
     if (rc) return rc;
     if (finish) {
         hipLaunchKernelGGL(k_finalize_rule, dim3(grid_for((int64_t)K * d, 256, 4096)), dim3(256), 0, st,
