@@ -25,6 +25,10 @@ elif which == "iid":
     img = bench.iid_image(8192, 8192, 1, dev)
     bh, K = 4, 256
     crop = img[:1024, :1024].contiguous()
+elif which == "g64":
+    img = bench.structured_image(8192, 8192, 7, dev)
+    bh, K = 8, 256
+    crop = img[:2048, :2048].contiguous()
 elif which == "rgb48":
     img = bench.structured_image(4096, 4096, 3, dev, channels=3)
     bh, K = 4, 256
