@@ -22,7 +22,8 @@ RUNTIME = r'''
 namespace emu {
 Block *g_block = nullptr;
 unsigned char g_lds[LDS_BYTES] __attribute__((aligned(256)));
-int g_cus = 4;
+// compute units the emulated device reports (VQ_EMU_CUS overrides: launches then take the forms they have on a large chip)
+int g_cus = std::getenv("VQ_EMU_CUS") ? std::atoi(std::getenv("VQ_EMU_CUS")) : 4;
 }
 thread_local emu::Idx threadIdx, blockIdx, blockDim, gridDim;
 '''

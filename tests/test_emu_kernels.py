@@ -134,6 +134,43 @@ def test_emu_lbg_iteration(eng, oracle, K, d, N, use_sorted):
     assert np.array_equal(eng.lbg_finalize(acc, T(cb)).numpy(), want["cb_out"])
 
 
+_MANY_CUS_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+sys.path.insert(0, sys.argv[1] + "/..")
+from emu_engine import EmuEngine, emulated_kernels
+from oracle import vq_oracle
+import torch
+vq_oracle.build()
+K, d, N = 32, 16, 54912
+rng = np.random.default_rng(3)
+cb = np.clip(rng.random((K, 1)) * 255.0 + rng.normal(0, 20, (K, d)), 0, 300)
+blocks = np.clip(cb[rng.integers(0, K, N)] + rng.normal(0, 14.0, (N, d)), 0, 255).astype(np.uint8)
+want = vq_oracle.lbg_iter(blocks, cb)
+with emulated_kernels():
+    eng = EmuEngine()
+    b = torch.from_numpy(blocks)
+    acc, dist, labels = eng.lbg_accum(b, torch.from_numpy(cb), want_labels=True, mode=1, sorted=eng.sort_blocks(b))
+a = acc.numpy().astype(np.uint64)
+assert np.array_equal(labels.numpy(), want["labels"]), "labels"
+assert np.array_equal(a[: K * d].reshape(K, d), want["sums"]) and np.array_equal(a[K * d:], want["counts"]), "sums"
+print("ok")
+"""
+
+
+def test_emu_lbg_iteration_one_tile_per_workgroup_odd_tiles_per_window():
+    """The fused pass as a large chip launches it for a medium input: one 1536-vector tile per workgroup (five and a
+    third per sort window), 40 workgroups, the tiles of every XCD's share taken middle-out.  The emulated device
+    reports 16 compute units in this process (with the default 4 the same input takes the resident-workgroup form)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, VQ_EMU_CUS="16")
+    r = subprocess.run([sys.executable, "-c", _MANY_CUS_SCRIPT, os.path.dirname(os.path.abspath(__file__))], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_emu_decode_pack_split_sum(eng, oracle):
     rng = np.random.default_rng(2)
     K, bh, bw, C = 20, 2, 4, 3

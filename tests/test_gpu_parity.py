@@ -402,6 +402,24 @@ def test_lbg_iteration_pruned(eng, oracle, K, d):
     assert dist.item() == oracle.numpy_sum(want["min_dist"])
 
 
+@pytest.mark.parametrize("K,d,N", [(64, 16, 54912), (100, 24, 54912), (64, 16, 61440), (32, 12, 122880), (64, 16, 486000),
+                                   (256, 16, 491520)])
+def test_lbg_iteration_pruned_tile_counts(eng, oracle, K, d, N):
+    """Launches whose workgroup tiles do not divide the sort window (the fused pass takes 1536 vectors per workgroup,
+    five and a third per window) at the tile counts where the kernel re-orders the tiles of an XCD's share: every
+    tile must still be visited exactly once."""
+    rng = np.random.default_rng(K + d + N)
+    cb = np.clip(rng.random((K, 1)) * 255.0 + rng.normal(0, 25, (K, d)), 0, 255)
+    blocks = np.clip(cb[rng.integers(0, K, N)] + rng.normal(0, 12, (N, d)), 0, 255).astype(np.uint8)
+    want = oracle.lbg_iter(blocks, cb)
+    b = dev(blocks)
+    acc, dist, labels = eng.lbg_accum(b, dev(cb), want_labels=True, mode=1, sorted=eng.sort_blocks(b))
+    acc_h = acc.cpu().numpy().astype(np.uint64)
+    assert np.array_equal(labels.cpu().numpy(), want["labels"])
+    assert np.array_equal(acc_h[: K * d].reshape(K, d), want["sums"])
+    assert np.array_equal(acc_h[K * d:], want["counts"])
+    assert dist.item() == oracle.numpy_sum(want["min_dist"])
+
 
 # ---------------------------------------------------------------------------------------------------
 # full training, through the reference-shaped Codebook class

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Random shapes on the GPU: FAST search (plain, pruned, image-fused) and the fused LBG pass against the all-fp64
-EXACT search of the same library (itself pinned to the CPU oracle by the test-suite).
+"""Random shapes on the GPU: FAST search (plain, pruned, image-fused), the fused LBG pass and a three-iteration training
+stage against the all-fp64 EXACT search of the same library (itself pinned to the CPU oracle by the test-suite).
 Usage: python3 tools/gpu_fuzz.py [seconds] [seed]"""
 import os, sys, time
 import numpy as np
@@ -22,6 +22,8 @@ while time.time() < t_end:
     K = int(rng.choice([1, 2, 7, 16, 31, 32, 33, 64, 100, 255, 256, 257, 400, 512, 513, 1000, 1024, 1500, 4096, 4097, 5000]))
     H = int(rng.integers(bh, 40 * bh)) if rng.random() < 0.5 else int(rng.integers(1, 200))
     W = int(rng.integers(bw, 60 * bw)) if rng.random() < 0.5 else int(rng.integers(1, 300))
+    if rng.random() < 0.25:                      # several sort windows, the last one partly filled
+        H, W = int(rng.integers(100 * bh, 260 * bh)), int(rng.integers(100 * bw, 260 * bw))
     if rng.random() < 0.4:                       # aligned sizes take the fast paths
         H, W = (H // (4 * bh) + 1) * 4 * bh, (W // 16 + 1) * 16
     kind = rng.integers(0, 3)
@@ -51,6 +53,8 @@ while time.time() < t_end:
     got_l, got_d = eng.encode_image(timg, bh, bw, tcb, want_dist=True)
     assert torch.equal(got_l, want_l) and torch.equal(got_d, want_d), "image-fused differs, " + tag
     srt2, _ = eng.sort_image(timg, bh, bw)
+    os.makedirs("gpurun_out", exist_ok=True)
+    np.savez("gpurun_out/fuzz_last_case.npz", img=img, cb=cb, bh=bh, bw=bw)   # what to look at after a failure
     acc, dist, lab = eng.lbg_accum(None if (srt2 is not None and eng.prune_supported(K, d)) else blocks, tcb, want_labels=True,
                                    sorted=srt2, shape=(N, d))
     assert torch.equal(lab, want_l), "LBG labels differ, " + tag
@@ -61,6 +65,13 @@ while time.time() < t_end:
     ref = tcb.trunc().to(torch.int64).remainder(256).to(torch.uint8)[want_l.long()].view(-(-H // bh), -(-W // bw), bh, bw, C)
     ref = ref.permute(0, 2, 1, 3, 4).reshape(dec.shape)
     assert torch.equal(dec, ref), "decode differs, " + tag
+    # a training stage: FAST on the sorted copy against the all-fp64 search on the block matrix, three iterations
+    if K >= 2 and N >= K:
+        cb0 = torch.from_numpy(b_np[pick].astype(np.float64) * (1.0 + 0.01 * rng.choice([-1.0, 1.0], size=(K, 1)))).to(dev)
+        want_cb, want_D, want_conv = eng.lbg_stage(blocks, cb0, N * d, 0.001, 3, mode=0)
+        got_cb, got_D, got_conv = eng.lbg_stage(None if (srt2 is not None and eng.prune_supported(K, d)) else blocks, cb0, N * d,
+                                                0.001, 3, sorted=srt2, shape=(N, d), mode=1)
+        assert torch.equal(got_cb, want_cb) and got_D == want_D and got_conv == want_conv, "training stage differs, " + tag
     cases += 1
     if cases % 20 == 0:
         print(f"{cases} cases ok, last: {tag}", flush=True)

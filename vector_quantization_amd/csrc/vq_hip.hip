@@ -2065,9 +2065,12 @@ __global__ __launch_bounds__(ACC ? 1024 : 512) VQ_ASSIGN_ATTR VQ_ACC_ATTR(ACC) v
             // stretch of that many classes backwards puts long and short workgroups together
             if (a.heavy_first == 2 && nwin <= 32 && 32 % nwin == 0) {
                 const uint32_t m = 32 / nwin;
-                if ((c / m) & 1) c = (c / m) * m + (m - 1 - c % m);
+                if (TPW % m == 0 && ((c / m) & 1)) c = (c / m) * m + (m - 1 - c % m);
             }
-            const uint32_t pos = (c & 1) ? TPW / 2 + (c >> 1) : TPW / 2 - 1 - (c >> 1);
+            // classes 0, 1, 2, ... -> the middle tile, then its right and left neighbours in turn: a permutation of the
+            // window's TPW tiles whether TPW is even or odd (12-wave workgroups take 5 tiles and a third per window)
+            const uint32_t mid = (TPW - 1) / 2;
+            const uint32_t pos = (c & 1) ? mid + 1 + (c >> 1) : mid - (c >> 1);
             first_tile = (int64_t)(blockIdx.x & 7) * tx + (int64_t)w * TPW + pos;
         }
     }
