@@ -6,9 +6,10 @@ import os, sys, time
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from vector_quantization_amd import HipEngine
+from vector_quantization_amd import HipEngine, train_lbg
 dev = torch.device("cuda:0")
 eng = HipEngine(dev)
+eng_exact = HipEngine(dev, mode="exact")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t_end = time.time() + budget
@@ -22,8 +23,12 @@ while time.time() < t_end:
     K = int(rng.choice([1, 2, 7, 16, 31, 32, 33, 64, 100, 255, 256, 257, 400, 512, 513, 1000, 1024, 1500, 4096, 4097, 5000]))
     H = int(rng.integers(bh, 40 * bh)) if rng.random() < 0.5 else int(rng.integers(1, 200))
     W = int(rng.integers(bw, 60 * bw)) if rng.random() < 0.5 else int(rng.integers(1, 300))
-    if rng.random() < 0.25:                      # several sort windows, the last one partly filled
+    u = rng.random()
+    if u < 0.25:                                 # several sort windows, the last one partly filled
         H, W = int(rng.integers(100 * bh, 260 * bh)), int(rng.integers(100 * bw, 260 * bw))
+    elif u < 0.29 and d <= 48:                   # up to a few million vectors: launches of many rounds of workgroups
+        H, W = int(rng.integers(400 * bh, 1800 * bh)), int(rng.integers(400 * bw, 1800 * bw))
+        K = min(K, 1500)
     if rng.random() < 0.4:                       # aligned sizes take the fast paths
         H, W = (H // (4 * bh) + 1) * 4 * bh, (W // 16 + 1) * 16
     kind = rng.integers(0, 3)
@@ -72,6 +77,14 @@ while time.time() < t_end:
         got_cb, got_D, got_conv = eng.lbg_stage(None if (srt2 is not None and eng.prune_supported(K, d)) else blocks, cb0, N * d,
                                                 0.001, 3, sorted=srt2, shape=(N, d), mode=1)
         assert torch.equal(got_cb, want_cb) and got_D == want_D and got_conv == want_conv, "training stage differs, " + tag
+    # now and then a whole training run (VQ_Full.py:60-98): FAST engine against the all-fp64 engine
+    if cases % 7 == 0 and N >= 8:
+        k = int(rng.choice([2, 3, 8, 20, 64, 130])) if N < 200000 else int(rng.choice([8, 64]))
+        k = min(k, N)
+        got = train_lbg(eng, blocks, k, max_iterations=6, log=None)
+        want = train_lbg(eng_exact, blocks, k, max_iterations=6, log=None)
+        assert torch.equal(got.codebook, want.codebook) and got.distortions == want.distortions and \
+            got.iters_per_stage == want.iters_per_stage, "training run differs, " + tag + f" k={k}"
     cases += 1
     if cases % 20 == 0:
         print(f"{cases} cases ok, last: {tag}", flush=True)
