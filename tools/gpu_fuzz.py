@@ -10,6 +10,27 @@ from vector_quantization_amd import HipEngine, train_lbg
 dev = torch.device("cuda:0")
 eng = HipEngine(dev)
 eng_exact = HipEngine(dev, mode="exact")
+from vector_quantization_amd._lib import lib, last_error, VQ_E_UNSUPPORTED  # noqa: E402
+from vector_quantization_amd.lbg import shards_chunk_aligned  # noqa: E402
+import ctypes  # noqa: E402
+
+
+def P(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def STREAM():
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+group = None
+if os.environ.get("VQ_FUZZ_GROUP") == "1":       # also the multi-GPU form of the training stage, on a group of one rank
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    group = dist.group.WORLD
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t_end = time.time() + budget
@@ -39,7 +60,14 @@ while time.time() < t_end:
         base = 128 + 100 * np.sin(xx / 17.0 + rng.random() * 6) * np.cos(yy / 11.0) + rng.normal(0, 4 if kind == 1 else 0.5, (H, W))
         img = np.clip(np.stack([base + 9 * c for c in range(C)], -1), 0, 255).astype(np.uint8)
     timg = torch.from_numpy(img).to(dev)
-    blocks = eng.blocks_from_image(timg, bh, bw)
+    pad = int(rng.integers(0, 2))                # edge replication (VQ_Full.py:23-33) or zeros (old/CodeBook_VQ.py)
+    blocks = eng.blocks_from_image(timg, bh, bw, pad)
+    # the block matrix itself, against plain tensor indexing
+    nr, nc = -(-H // bh), -(-W // bw)
+    padded = torch.nn.functional.pad(timg.permute(2, 0, 1)[None].float(), (0, nc * bw - W, 0, nr * bh - H),
+                                     mode="replicate" if pad == 0 else "constant")[0].permute(1, 2, 0).to(torch.uint8)
+    ref_blocks = padded.view(nr, bh, nc, bw, C).permute(0, 2, 1, 3, 4).reshape(nr * nc, d)
+    assert torch.equal(blocks, ref_blocks), f"blocks differ, H={H} W={W} C={C} {bh}x{bw} pad={pad}"
     N = blocks.shape[0]
     b_np = blocks.cpu().numpy()
     pick = rng.integers(0, N, K)
@@ -48,16 +76,16 @@ while time.time() < t_end:
         cb[K // 2] = cb[0]                       # duplicate row
     tcb = torch.from_numpy(cb).to(dev)
     want_l, want_d = eng.encode(blocks, tcb, want_dist=True, mode=0)
-    tag = f"case {cases}: H={H} W={W} C={C} {bh}x{bw} d={d} K={K} N={N} kind={kind}"
+    tag = f"case {cases}: H={H} W={W} C={C} {bh}x{bw} d={d} K={K} N={N} kind={kind} pad={pad}"
     got_l, got_d = eng.encode(blocks, tcb, want_dist=True, mode=1)
     assert torch.equal(got_l, want_l) and torch.equal(got_d, want_d), "plain FAST differs, " + tag
     srt = eng.sort_blocks(blocks)
     if srt is not None:
         got_l, got_d = eng.encode(blocks, tcb, want_dist=True, mode=1, sorted=srt)
         assert torch.equal(got_l, want_l) and torch.equal(got_d, want_d), "pruned FAST differs, " + tag
-    got_l, got_d = eng.encode_image(timg, bh, bw, tcb, want_dist=True)
+    got_l, got_d = eng.encode_image(timg, bh, bw, tcb, pad, want_dist=True)
     assert torch.equal(got_l, want_l) and torch.equal(got_d, want_d), "image-fused differs, " + tag
-    srt2, _ = eng.sort_image(timg, bh, bw)
+    srt2, _ = eng.sort_image(timg, bh, bw, pad)
     os.makedirs("gpurun_out", exist_ok=True)
     np.savez("gpurun_out/fuzz_last_case.npz", img=img, cb=cb, bh=bh, bw=bw)   # what to look at after a failure
     acc, dist, lab = eng.lbg_accum(None if (srt2 is not None and eng.prune_supported(K, d)) else blocks, tcb, want_labels=True,
@@ -70,6 +98,24 @@ while time.time() < t_end:
     ref = tcb.trunc().to(torch.int64).remainder(256).to(torch.uint8)[want_l.long()].view(-(-H // bh), -(-W // bw), bh, bw, C)
     ref = ref.permute(0, 2, 1, 3, 4).reshape(dec.shape)
     assert torch.equal(dec, ref), "decode differs, " + tag
+    # the bit-packed label stream (VQ_Full.py:134-147) and back
+    packed = eng.pack_labels(want_l, K)
+    bits = 0 if K <= 1 else int(K - 1).bit_length()
+    if bits:
+        lab_np = want_l.cpu().numpy().astype(np.uint64)
+        stream_bits = ((lab_np[:, None] >> np.arange(bits - 1, -1, -1, dtype=np.uint64)[None, :]) & 1).astype(np.uint8).reshape(-1)
+        assert np.array_equal(packed.cpu().numpy(), np.packbits(stream_bits)), "packed labels differ, " + tag
+    else:
+        assert packed.numel() == 0, "packed labels of K = 1 are not empty, " + tag
+    assert torch.equal(eng.unpack_labels(packed, N, K), want_l), "unpacked labels differ, " + tag
+    # the entry point that allocates nothing
+    lab_s = torch.full((N,), -7, dtype=torch.int32, device=dev)
+    dist_s = torch.full((N,), -1.0, dtype=torch.float64, device=dev)
+    rc = lib.vq_encode_l1_static(P(blocks), N, d, P(tcb), K, P(lab_s), P(dist_s), 1, STREAM())
+    if rc == 0:
+        assert torch.equal(lab_s, want_l) and torch.equal(dist_s, want_d), "static-scratch search differs, " + tag
+    else:
+        assert rc == VQ_E_UNSUPPORTED, f"vq_encode_l1_static: {last_error()}, " + tag
     # a training stage: FAST on the sorted copy against the all-fp64 search on the block matrix, three iterations
     if K >= 2 and N >= K:
         cb0 = torch.from_numpy(b_np[pick].astype(np.float64) * (1.0 + 0.01 * rng.choice([-1.0, 1.0], size=(K, 1)))).to(dev)
@@ -77,6 +123,13 @@ while time.time() < t_end:
         got_cb, got_D, got_conv = eng.lbg_stage(None if (srt2 is not None and eng.prune_supported(K, d)) else blocks, cb0, N * d,
                                                 0.001, 3, sorted=srt2, shape=(N, d), mode=1)
         assert torch.equal(got_cb, want_cb) and got_D == want_D and got_conv == want_conv, "training stage differs, " + tag
+        if group is not None:                    # the two-halves form of the iteration, collectives of a one-rank group between
+            aligned, sizes = shards_chunk_aligned(N, group, dev)
+            for limit_bytes in (1 << 20, 0):     # both exchange routes
+                got_cb, got_D, got_conv = eng.lbg_stage_group(blocks, cb0, N * d, 0.001, 3, group, sizes, aligned, sorted=srt2,
+                                                              shape=(N, d), mode=1, allreduce_from_bytes=limit_bytes)
+                assert torch.equal(got_cb, want_cb) and got_D == want_D and got_conv == want_conv, \
+                    f"training stage in two halves (route {limit_bytes}) differs, " + tag
     # now and then a whole training run (VQ_Full.py:60-98): FAST engine against the all-fp64 engine
     if cases % 7 == 0 and N >= 8:
         k = int(rng.choice([2, 3, 8, 20, 64, 130])) if N < 200000 else int(rng.choice([8, 64]))
@@ -89,3 +142,5 @@ while time.time() < t_end:
     if cases % 20 == 0:
         print(f"{cases} cases ok, last: {tag}", flush=True)
 print(f"fuzz ok: {cases} cases in {budget:.0f} s")
+if group is not None:
+    torch.distributed.destroy_process_group()
