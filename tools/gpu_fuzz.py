@@ -45,9 +45,11 @@ while time.time() < t_end:
     H = int(rng.integers(bh, 40 * bh)) if rng.random() < 0.5 else int(rng.integers(1, 200))
     W = int(rng.integers(bw, 60 * bw)) if rng.random() < 0.5 else int(rng.integers(1, 300))
     u = rng.random()
-    if u < 0.25:                                 # several sort windows, the last one partly filled
+    if u < 0.28:                                 # several sort windows, the last one partly filled
         H, W = int(rng.integers(100 * bh, 260 * bh)), int(rng.integers(100 * bw, 260 * bw))
-    elif u < 0.29 and d <= 48:                   # up to a few million vectors: launches of many rounds of workgroups
+    elif u < 0.32:                               # 0.1 .. 0.6 M vectors of any length, any codebook size
+        H, W = int(rng.integers(300 * bh, 780 * bh)), int(rng.integers(300 * bw, 780 * bw))
+    elif u < 0.36 and d <= 48:                   # up to a few million vectors: launches of many rounds of workgroups
         H, W = int(rng.integers(400 * bh, 1800 * bh)), int(rng.integers(400 * bw, 1800 * bw))
         K = min(K, 1500)
     if rng.random() < 0.4:                       # aligned sizes take the fast paths
