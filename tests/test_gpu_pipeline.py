@@ -67,3 +67,37 @@ def test_pipeline_results_without_waiting_are_complete_after_synchronize():
         ref = eng.encode_image(imgs[i], 4, 4, cb)
         assert torch.equal(res[i].labels, ref)
         assert torch.equal(res[i].decoded, eng.decode(ref.view(128, 128), cb, 4, 4, 3))
+
+
+def test_result_read_after_wait_survives_the_lanes_next_image():
+    """wait(result) followed by a read on the caller's stream, while that stream is held up behind a long image on
+    another lane; the result's lane meanwhile gets its next image (same shape, so the same buffers) with
+    inputs_ready=True.  The lane must not overwrite the labels before the pending read has happened."""
+    from vector_quantization_amd import HipEngine, EncodePipeline
+    dev = torch.device("cuda:0")
+    eng = HipEngine(dev)
+    rng = np.random.default_rng(77)
+    big = torch.from_numpy(_image(2048, 2048, 1, 3)).to(dev).repeat(8, 8, 1).contiguous()    # 16384 x 16384
+    x = torch.from_numpy(_image(96, 96, 1, 4)).to(dev)
+    y = torch.from_numpy(_image(96, 96, 1, 5)).to(dev)
+    cb_big = torch.from_numpy(rng.random((1024, 16)) * 255.0).to(dev)
+    cb = torch.from_numpy(rng.random((64, 16)) * 255.0).to(dev)
+    want_x = eng.encode_image(x, 4, 4, cb).clone()
+    want_y = eng.encode_image(y, 4, 4, cb).clone()
+    assert not torch.equal(want_x, want_y)
+    torch.cuda.synchronize(dev)
+    for _ in range(3):
+        pipe = EncodePipeline(dev, lanes=2)
+        r_big = pipe.submit(big, 4, 4, cb_big, inputs_ready=True)       # lane 0: more than a millisecond
+        r_x = pipe.submit(x, 4, 4, cb, inputs_ready=True)               # lane 1: done long before
+        pipe.wait(r_big)
+        keep = r_big.labels.clone()                                     # the caller's stream now waits for lane 0
+        pipe.wait(r_x)
+        got_x = r_x.labels.clone()                                      # ... and reads lane 1's labels after that
+        pipe.submit(big, 4, 4, cb_big, inputs_ready=True)               # lane 0 again
+        r_y = pipe.submit(y, 4, 4, cb, inputs_ready=True)               # lane 1 again: same buffers as x
+        pipe.wait(r_y)
+        got_y = r_y.labels.clone()
+        pipe.synchronize()
+        torch.cuda.synchronize(dev)
+        assert torch.equal(got_x, want_x) and torch.equal(got_y, want_y) and keep.numel() == 4096 * 4096

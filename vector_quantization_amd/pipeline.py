@@ -37,6 +37,7 @@ class EncodePipeline:
         self._scratch = [None] * lanes
         self._labels = [None] * lanes
         self._out = [None] * lanes
+        self._readers = [None] * lanes        # per lane: the stream that wait() made a consumer of its last result
         self._next = 0
 
     @property
@@ -56,25 +57,37 @@ class EncodePipeline:
         self._next = (k + 1) % len(self.engines)
         eng, stream = self.engines[k], self.streams[k]
         need = max(int(lib.vq_sorted_bytes(int(d), int(N))), N * d, 16)
-        if self._scratch[k] is None or self._scratch[k].numel() < need:
-            self._scratch[k] = torch.empty(need, dtype=torch.uint8, device=self.device)
-        if self._labels[k] is None or self._labels[k].numel() != N:
-            self._labels[k] = torch.empty(N, dtype=torch.int32, device=self.device)
         shape = (nr * bh, nc * bw, C)
-        if decode and (self._out[k] is None or tuple(self._out[k].shape) != shape):
-            self._out[k] = torch.empty(shape, dtype=torch.uint8, device=self.device)
         # the lane starts after whatever the caller has enqueued so far (the image, the codebook)
         if not inputs_ready:
             stream.wait_stream(torch.cuda.current_stream(self.device))
+        # a stream that wait() handed this lane's previous result to may still be reading it: the lane's buffers are
+        # overwritten only after what that stream has enqueued so far
+        if self._readers[k] is not None:
+            stream.wait_stream(self._readers[k])
+            self._readers[k] = None
         with torch.cuda.stream(stream):
+            # The lane's buffers are allocated with the lane's stream current: when an image of another shape replaces
+            # one of them, the allocator hands the old block only to later work of this same stream, never to another
+            # lane whose kernels could overlap with this lane's pending ones.
+            if self._scratch[k] is None or self._scratch[k].numel() < need:
+                self._scratch[k] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            if self._labels[k] is None or self._labels[k].numel() != N:
+                self._labels[k] = torch.empty(N, dtype=torch.int32, device=self.device)
+            if decode and (self._out[k] is None or tuple(self._out[k].shape) != shape):
+                self._out[k] = torch.empty(shape, dtype=torch.uint8, device=self.device)
             labels = eng.encode_image(img, bh, bw, cb, pad_mode=pad_mode, scratch=self._scratch[k], labels=self._labels[k])
             decoded = eng.decode(labels.view(nr, nc), cb, bh, bw, C, out=self._out[k]) if decode else None
         return PipelineResult(labels, decoded, k)
 
     def wait(self, result):
         """The caller's current stream waits for this result (for everything enqueued on its lane so far; no event
-        is recorded per image: an event record is a release fence in the middle of the lane's work)."""
-        torch.cuda.current_stream(self.device).wait_stream(self.streams[result.lane])
+        is recorded per image: an event record is a release fence in the middle of the lane's work).  The next submit
+        on that lane in turn waits for what the caller's stream has enqueued until then -- reads of the result enqueued
+        right after wait() are safe, also with inputs_ready=True; a consumer on any other stream has to order itself."""
+        reader = torch.cuda.current_stream(self.device)
+        reader.wait_stream(self.streams[result.lane])
+        self._readers[result.lane] = reader
 
     def synchronize(self):
         for s in self.streams:
