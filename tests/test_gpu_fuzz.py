@@ -18,3 +18,12 @@ def test_random_shapes_for_twenty_seconds(seed):
                        capture_output=True, text=True, timeout=110)
     tail = r.stdout[-1500:] + r.stderr[-3000:]
     assert r.returncode == 0 and "fuzz ok" in r.stdout, tail
+
+
+def test_random_small_images_against_the_cpu_oracle_for_fifteen_seconds():
+    """tests/gpu_fuzz_oracle.py: block matrix, whole training runs, search, decode and packed labels of random small
+    images against the CPU oracle."""
+    r = subprocess.run([sys.executable, "-u", os.path.join(ROOT, "tests", "gpu_fuzz_oracle.py"), "15", "9"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=110)
+    tail = r.stdout[-1500:] + r.stderr[-3000:]
+    assert r.returncode == 0 and "oracle fuzz ok" in r.stdout, tail
