@@ -77,6 +77,15 @@ while time.time() < t_end:
     dec = eng.decode(got_l.view(nr, nc), tcb, bh, bw, C)
     assert np.array_equal(dec.cpu().numpy(), vq_oracle.decode_u8(want_l.reshape(nr, nc), cb, bh, bw, C)), "decode differs, " + tag
     assert np.array_equal(eng.pack_labels(got_l, K).cpu().numpy(), vq_oracle.pack_labels(want_l, K)), "packed labels differ, " + tag
+    # per-cluster sums / counts for given labels, the centroid update and the split on their own
+    ws, wc = vq_oracle.accumulate(want_blocks, want_l, K)
+    acc = eng.accum_labels(blocks, got_l, K)
+    acc_h = acc.cpu().numpy().astype(np.uint64)
+    assert np.array_equal(acc_h[: K * d].reshape(K, d), ws) and np.array_equal(acc_h[K * d:], wc), "sums for given labels differ, " + tag
+    assert np.array_equal(eng.lbg_finalize(acc, tcb).cpu().numpy(), vq_oracle.finalize(ws, wc, cb)), "centroid update differs, " + tag
+    assert np.array_equal(eng.lbg_split(tcb, eps).cpu().numpy(), vq_oracle.split(cb, eps)), "split differs, " + tag
+    assert np.array_equal(eng.colsum(blocks).cpu().numpy().astype(np.uint64), vq_oracle.colsum_u8(want_blocks)), "column sums differ, " + tag
+    assert float(eng.numpy_sum(got_d).item()) == vq_oracle.numpy_sum(want_d), "numpy-order sum differs, " + tag
     cases += 1
     if cases % 50 == 0:
         print(f"{cases} cases ok, last: {tag}", flush=True)
