@@ -189,8 +189,25 @@ def iid_image(h, w, seed, device):
     return torch.randint(0, 256, (h, w), device=device, generator=g, dtype=torch.uint8)
 
 
+PREROLL_MS = 25.0
+
+
+def preroll(fn, device, ms=PREROLL_MS):
+    """Untimed set-up before a measurement: fn() back to back for `ms` of wall time.  After any pause the card needs
+    about 13 ms of continuous work to reach its sustained clock (tools/clock_ramp.py: the encode step takes 0.18 - 0.22 ms
+    right after a pause of 50 ms or more and 0.169 ms from the 80th consecutive step on); a measurement of a few
+    milliseconds taken cold reads 5 % low."""
+    import torch
+    t_end = time.perf_counter() + ms * 1e-3
+    while time.perf_counter() < t_end:
+        for _ in range(16):
+            fn()
+        torch.cuda.synchronize(device)
+
+
 def event_ms(fn, reps, device):
     import torch
+    preroll(fn, device)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     for a, b in ev:
         a.record()
@@ -224,6 +241,7 @@ def search_profile(eng, img, bh, bw, cb, reps, device, check_vectors=1 << 18):
     for _ in range(2):
         eng.encode_prepared(blocks, prepared, **kw)
     # the filter kernel alone: HIP events recorded by the library right around that launch, on its stream
+    preroll(lambda: eng.encode_prepared(blocks, prepared, phases=1, **kw), device)
     filter_ms = eng.search_kernel_ms(lambda: eng.encode_prepared(blocks, prepared, phases=1, **kw), reps)
     queued, pairs_eval = eng.search_statistics(prepared, N)
     in_filter = bool(pruned and eng.prune_resolves_in_filter(K, d))     # near-ties settled inside the filter kernel
@@ -319,6 +337,9 @@ def main():
     def step():
         return pipe.submit(img, BH, BW, cb, inputs_ready=True)    # (resident before the timed region starts)
 
+    # untimed set-up: every lane allocates its buffers and runs once, and the card is brought to its sustained clock
+    # (see preroll); then the W warm-up steps and the K timed ones
+    preroll(step, device)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -339,6 +360,7 @@ def main():
         eng.encode_image(img, BH, BW, cb, scratch=scratch, labels=labels)
         return eng.decode(labels.view(nr, nc), cb, BH, BW, 1)
 
+    preroll(step_sequential, device)
     for _ in range(args.warmup):
         step_sequential()
     barrier()
@@ -357,6 +379,7 @@ def main():
     # the measure of what pruning saves
     blocks = eng.blocks_from_image(img, BH, BW)
     lab_full = torch.empty_like(labels)
+    preroll(lambda: eng.encode_prepared(blocks, prepared, labels=lab_full, phases=1), device)
     full_ms = eng.search_kernel_ms(lambda: eng.encode_prepared(blocks, prepared, labels=lab_full, phases=1), reps)
     _, pairs_full = eng.search_statistics(prepared, N)
     eng.encode_prepared(blocks, prepared, labels=lab_full)
@@ -434,7 +457,9 @@ def main():
     n_total = world * N
     cur = cb
     shard_info = shards_chunk_aligned(N, group, device) if distributed else None
-    lbg_steps = max(5, args.steps // 2)
+    # (a stage costs about 0.14 ms besides its iterations -- state reset, the first codebook preparation, the read of
+    # the last record --, so a short stage reads low: at least 100 iterations are timed whatever --steps says)
+    lbg_steps = max(100, args.steps // 2)
 
     def lbg_run(cur, steps):
         if distributed:
@@ -446,7 +471,7 @@ def main():
         # (threshold < 0: it never holds), iteration j + 1 enqueued before the outcome of iteration j is read
         return eng.lbg_stage(blocks, cur, n_total, -1.0, steps, sorted=srt)[0]
 
-    cur = lbg_run(cur, 3)
+    cur = lbg_run(cur, 128)                                      # untimed: warm-up and the card's clock (see preroll)
     barrier()
     t0 = time.perf_counter()
     cur = lbg_run(cur, lbg_steps)
@@ -459,6 +484,7 @@ def main():
     # the dominant kernel of an iteration alone: the pruned search with the per-cluster accumulation and the winners'
     # fp64 distances fused in (HIP events recorded by the library around that launch)
     # (as a training stage launches it: no labels written, distances left in sorted order)
+    lbg_run(cur, 128)
     acc_ms = eng.search_kernel_ms(lambda: eng.lbg_stage(None, cb, N, -1.0, 1, sorted=srt, shape=(N, d)), 20)
     _, acc_pairs = eng.search_statistics((cb, eng._workspace(K_CODEBOOK, d, N)), N)
     acc_ops = (2.0 * d) * float(acc_pairs) + float(d) * N        # SAD work of the evaluated pairs + d byte sums per vector
@@ -496,6 +522,9 @@ def main():
                    "parallelism": f"dp{world} (block vectors sharded by image, codebook replicated)"},
         "step_issue": f"consecutive steps alternate between {max(1, args.lanes)} HIP streams (EncodePipeline); every step "
                       "runs all of its kernels; one stream: sequential_ms_per_step",
+        "setup": f"before every timed region the same work runs untimed for {PREROLL_MS:.0f} ms (each pipeline lane allocates "
+                 "and runs once; the card reaches its sustained clock after about 13 ms of continuous work, "
+                 "tools/clock_ramp.py), then the W warm-up steps, then the K timed steps",
         "sequential_ms_per_step": sequential_ms,
         "sequential_vectors_per_s_per_gpu": N / (sequential_ms * 1e-3),
         "sequential_labels_equal": sequential_labels_equal,
